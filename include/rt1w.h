@@ -1,0 +1,193 @@
+/* rt1w.h -- C ABI of the MI355X path tracer (librt1w.so).
+ *
+ * The reference (hatoo/raytracing-1w, /root/reference) has NO FFI or plugin
+ * interface: the hot path is a closure inlined in `main`
+ * (src/main.rs:957-1001) over `camera`, `world: BVHNode`,
+ * `lights: Option<Vec<Box<dyn Hittable>>>`, `background`, image size, spp and
+ * MAX_DEPTH.  This header is the seam a Rust host would bind with
+ * `extern "C"`: the scene is described through constructors that mirror the
+ * reference's own (same names, same argument order and meaning), flattened
+ * once, uploaded once, and `rt1w_render` replaces the closure.
+ * INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - every function returns an `int`: >= 0 success (an id where the function
+ *     creates something), < 0 one of RT1W_ERR_*; `rt1w_last_error()` returns a
+ *     thread-local message.  Nothing aborts or throws across the ABI; the
+ *     reference's panics (src/bvh.rs:61,67, src/hittable.rs:153) become
+ *     RT1W_ERR_INVALID.
+ *   - caller owns every buffer it passes; the library copies what it keeps.
+ *   - a scene is immutable after rt1w_scene_commit and may back many contexts;
+ *     one context = one GPU + one HIP stream; calls on distinct contexts are
+ *     thread-safe, calls on one context are serialised by the caller.
+ *   - there is no CPU render path: without a usable GPU rt1w_context_create
+ *     fails with RT1W_ERR_DEVICE.
+ *   - all geometry/colour arithmetic is f64 (`type Float = f64`, src/main.rs:1).
+ */
+#ifndef RT1W_H
+#define RT1W_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT1W_OK 0
+#define RT1W_ERR_INVALID (-1)     /* bad argument / bad id / empty BVH (src/bvh.rs:61) */
+#define RT1W_ERR_UNSUPPORTED (-2) /* graph shape the device format cannot express */
+#define RT1W_ERR_DEVICE (-3)      /* no GPU, HIP error */
+#define RT1W_ERR_NOMEM (-4)
+#define RT1W_ERR_STATE (-5)       /* e.g. mutate after commit, render before commit */
+
+typedef struct rt1w_scene rt1w_scene;
+typedef struct rt1w_context rt1w_context;
+
+const char* rt1w_last_error(void);
+const char* rt1w_version(void);
+
+/* ---- scene construction: one-shot host work (src/main.rs:192-795, 807-951) ---- */
+
+/* `build_seed` seeds the scene-build random stream that replaces the
+ * reference's entropy-seeded `MyRng::from_entropy()` (src/main.rs:803).  Every
+ * constructor below that takes `rng` in the reference (AABox::new, BVHNode::new,
+ * NoiseTexture::new) draws from it at call time, in call order, exactly like
+ * the Rust constructors do. */
+int rt1w_scene_create(uint64_t build_seed, rt1w_scene** out);
+void rt1w_scene_destroy(rt1w_scene* s);
+
+/* draws for the host's own scene code (`rng.gen()`, `rng.gen_range(a..b)` in
+ * random_scene / final_scene, src/main.rs:212-245,653,777-779) from the same
+ * build stream; value returned through *out */
+int rt1w_scene_rng_f64(rt1w_scene* s, double* out);
+int rt1w_scene_rng_range(rt1w_scene* s, double low, double high, double* out);
+
+/* Texture implementors (src/texture.rs).  Return a texture id. */
+int rt1w_texture_solid(rt1w_scene* s, const double rgb[3]);                 /* SolidColor   texture.rs:13-16 */
+int rt1w_texture_checker(rt1w_scene* s, int odd, int even);                 /* CheckerTexture texture.rs:18-22 */
+int rt1w_texture_noise(rt1w_scene* s, double scale);                        /* NoiseTexture256::new(scale, rng) texture.rs:32-38, perlin.rs:25-43 */
+int rt1w_texture_noise_tables(rt1w_scene* s, double scale, const double ranvec[768],
+                              const uint32_t perm_x[256], const uint32_t perm_y[256],
+                              const uint32_t perm_z[256]);                  /* same, caller-supplied tables */
+int rt1w_texture_image(rt1w_scene* s, const uint8_t* rgb8, uint32_t width, uint32_t height); /* DynamicImage texture.rs:67-89 (decoded RGB8, row 0 = top) */
+
+/* Material implementors (src/material.rs).  Return a material id. */
+int rt1w_material_lambertian(rt1w_scene* s, int albedo_texture);            /* material.rs:52-55 */
+int rt1w_material_metal(rt1w_scene* s, const double albedo[3], double fuzz);/* material.rs:57-61 */
+int rt1w_material_dielectric(rt1w_scene* s, double ir);                     /* material.rs:127-130 */
+int rt1w_material_diffuse_light(rt1w_scene* s, int emit_texture);           /* material.rs:63-66 */
+int rt1w_material_null(rt1w_scene* s);                                      /* impl Material for () material.rs:68 */
+
+/* Hittable implementors.  Return a hittable id.  A hittable id may be used as
+ * a child exactly once (the reference owns children by Box). */
+int rt1w_hittable_sphere(rt1w_scene* s, const double center[3], double radius, int material);  /* sphere.rs:16-20 */
+int rt1w_hittable_moving_sphere(rt1w_scene* s, const double center0[3], const double center1[3],
+                                double time0, double time1, double radius, int material);      /* moving_sphere.rs:13-20 */
+int rt1w_hittable_xy_rect(rt1w_scene* s, double x0, double x1, double y0, double y1, double k, int material); /* aarect.rs:15-22 */
+int rt1w_hittable_xz_rect(rt1w_scene* s, double x0, double x1, double z0, double z1, double k, int material); /* aarect.rs:25-32 */
+int rt1w_hittable_yz_rect(rt1w_scene* s, double y0, double y1, double z0, double z1, double k, int material); /* aarect.rs:35-42 */
+int rt1w_hittable_aabox(rt1w_scene* s, const double p0[3], const double p1[3], int material);  /* AABox::new aabox.rs:22-84 (draws rng) */
+int rt1w_hittable_translate(rt1w_scene* s, int child, const double offset[3]);                 /* hittable.rs:49-52 */
+int rt1w_hittable_rotate_y(rt1w_scene* s, int child, double time0, double time1, double angle_deg); /* RotateY::new hittable.rs:158-202 */
+int rt1w_hittable_flip_face(rt1w_scene* s, int child);                                         /* hittable.rs:61 */
+int rt1w_hittable_constant_medium(rt1w_scene* s, int boundary, double density, int texture);   /* ConstantMedium::new constant_medium.rs:22-28 */
+int rt1w_hittable_bvh(rt1w_scene* s, const int* children, uint32_t n, double time0, double time1); /* BVHNode::new bvh.rs:54-103 (draws rng) */
+
+/* what `main` hands to the pixel loop (src/main.rs:807-951) */
+int rt1w_scene_set_world(rt1w_scene* s, int hittable);
+int rt1w_scene_set_lights(rt1w_scene* s, const int* hittables, uint32_t n); /* n = 0: `lights = None` -> ray_color_without_light_objects */
+int rt1w_scene_set_background(rt1w_scene* s, const double rgb[3]);
+int rt1w_scene_set_camera(rt1w_scene* s, const double look_from[3], const double look_at[3],
+                          const double vup[3], double vfov_deg, double aspect_ratio,
+                          double aperture, double focus_dist, double time0, double time1); /* Camera::new camera.rs:22-59 */
+/* BVH is already built by the constructors; commit flattens the graph into the
+ * device record arrays and freezes the scene. */
+int rt1w_scene_commit(rt1w_scene* s);
+
+/* the scene table of `main` (src/main.rs:815-937): arm 0 random_scene, 1 two_spheres,
+ * 2 two_perlin_spheres, 3 earth, 4 simple_light, 5 cornel_box, 6 cornel_smoke,
+ * any other final_scene; built through the constructors above.  `aspect_ratio`
+ * is what `main` passes to Camera::new (1.0 for arms 5,6,7; 16/9 otherwise, or
+ * the caller's override).  `earth_rgb8` (1024x512 decoded assets/earthmap.jpg or
+ * any RGB8 image) is needed by arms 3 and 7, else may be NULL.
+ * `defaults[3]` receives the arm's image_width, image_height, samples_per_pixel. */
+int rt1w_scene_build_reference(int arm, uint64_t build_seed, double aspect_ratio,
+                               const uint8_t* earth_rgb8, uint32_t earth_w, uint32_t earth_h,
+                               rt1w_scene** out, uint32_t defaults[3]);
+
+/* introspection of the committed flat scene (tests, DESIGN.md numbers) */
+typedef struct rt1w_scene_info {
+    uint32_t n_nodes, n_lights, n_materials, n_textures, n_perlin;
+    uint32_t stack_need;   /* traversal stack entries the scene needs */
+    uint32_t scope_depth;  /* deepest wrapper nesting */
+    uint32_t has_media;
+    uint64_t bytes;        /* bytes uploaded per context */
+} rt1w_scene_info;
+int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out);
+/* copy of the flat arrays (the exact bytes a context uploads); `what`: 0 nodes,
+ * 1 lights, 2 materials, 3 textures, 4 perlin, 5 images, 6 camera+background.
+ * Returns bytes written, or needed size if buf==NULL. */
+int64_t rt1w_scene_copy_flat(const rt1w_scene* s, int what, void* buf, uint64_t cap);
+
+/* ---- execution (replaces src/main.rs:957-1001) ---- */
+
+int rt1w_device_count(void);
+int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out);
+void rt1w_context_destroy(rt1w_context* c);
+
+#define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
+
+typedef struct rt1w_render_params {
+    uint32_t width, height;         /* image_width, image_height (src/main.rs:799,939) */
+    uint32_t x0, y0, tile_w, tile_h;/* tile to render; y is the reference's row index j (j = height-1 is the TOP row of the PPM) */
+    uint32_t spp;                   /* samples_per_pixel rendered by this call */
+    uint32_t sample_offset;         /* first absolute sample index; 0 unless sharding samples */
+    uint32_t max_depth;             /* MAX_DEPTH = 50 (src/main.rs:801) */
+    uint32_t global_seed;
+    uint32_t chunk;                 /* samples per work item, 0 = library default (rt1w_default_chunk) */
+    uint32_t flags;                 /* RT1W_OUT_* */
+} rt1w_render_params;
+
+typedef struct rt1w_stats {
+    uint64_t paths;        /* pixels * spp */
+    uint64_t segments;     /* traced rays (camera + bounces) */
+    double kernel_ms;      /* HIP-event time of the render kernel(s) on the context's stream */
+    double total_ms;       /* host wall time of the call incl. device->host copy */
+    uint32_t chunk, n_chunks;
+    uint32_t grid, block;
+} rt1w_stats;
+
+/* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */
+uint32_t rt1w_default_chunk(uint32_t tile_w, uint32_t tile_h, uint32_t spp);
+
+/* Renders the tile into caller memory: out_rgb[(y - y0) * tile_w + (x - x0)][3],
+ * row 0 = j = y0.  Values are the reference's `pixel_color.into_sampled(spp)`
+ * (src/main.rs:992, color.rs:14-21), i.e. linear f64 means before gamma, or raw
+ * sums with RT1W_OUT_SUM. */
+int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, rt1w_stats* stats);
+/* same, but `d_out_rgb` is a device pointer on the context's GPU (e.g. a torch
+ * tensor); no host copy.  Synchronises the context's stream before returning. */
+int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out_rgb, rt1w_stats* stats);
+
+/* ---- output side (src/color.rs) ---- */
+
+/* Color::into_sampled (color.rs:14-21) over n pixels: NaN scrub of the SUM, then * 1/spp */
+int rt1w_resolve(const double* sums, uint64_t n_pixels, uint32_t spp, double* means);
+/* Display for SampledColor (color.rs:56-65): gamma-2, clamp, *256, truncate; n values -> n bytes */
+int rt1w_quantize(const double* means, uint64_t n_values, uint8_t* out);
+/* the whole P3 text of src/main.rs:953,1003-1007 for an image whose row 0 is j = 0
+ * (rows are emitted top-down, j = height-1 first).  Returns bytes written
+ * (excluding NUL) or needed size if buf==NULL. */
+int64_t rt1w_format_ppm(const double* means, uint32_t width, uint32_t height, char* buf, uint64_t cap);
+
+/* ---- diagnostics ---- */
+/* evaluates the numerical contract (include/rt1w_num.h) ON THE DEVICE for n inputs:
+ * fn 0 a/b, 1 sqrt|a|, 2 sin a, 3 cos a, 4 acos(a/(|a|+1)), 5 atan2(a,b), 6 log|b|,
+ * 7 first gen_f64 of stream (pixel=i, sample=(uint32)a_bits), 8 gen_range(-1,1) of same.
+ * Used by the GPU tests to prove host/device bit equality. */
+int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, double* out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

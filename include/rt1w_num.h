@@ -1,0 +1,366 @@
+/* rt1w_num.h -- the numerical contract shared by the HIP device code, the host
+ * scene code and the CPU oracle.
+ *
+ * Why this header exists: the north-star parity claim is "same f64 framebuffer,
+ * bit-identical PPM".  f64 + - * / sqrt are IEEE correctly rounded on x86-64 and
+ * on gfx950, so the only sources of CPU/GPU divergence are (a) fused
+ * multiply-add contraction, (b) vendor libm differences in the last ulp and
+ * (c) the random stream.  (a) is removed by building every translation unit
+ * with -ffp-contract=off; (b) and (c) are removed by defining the elementary
+ * functions and the generator HERE, in plain + - * / sqrt arithmetic with a
+ * fixed evaluation order, and compiling the same text for both sides.
+ *
+ * What of the reference this restates (all paths under /root/reference):
+ *   - per-pixel RNG seeding, src/main.rs:964 (`MyRng::seed_from_u64(j*W+i)`):
+ *     the reference generator is StdRng = ChaCha12 from the un-vendored crates
+ *     rand 0.8.4 / rand_chacha 0.3.1 / rand_core 0.6.3 (Cargo.lock).  The north
+ *     star replaces it with a counter-based Philox4x32-10 keyed by the same
+ *     pixel seed ("Philox-in-register RNG"); stream-level parity with ChaCha is
+ *     therefore out of scope, distribution-level parity is in scope.
+ *   - the *sampling shapes* of rand 0.8.4 on top of the word stream
+ *     (Standard f64, UniformFloat::sample_single, Standard bool,
+ *     UniformInt::sample_single_inclusive used by `choose`/`shuffle`/
+ *     `gen_range(0..=2)`), call sites src/main.rs:968-969, src/camera.rs:71,
+ *     src/math.rs:9-11,32,40-41,56-57, src/pdf.rs:63, src/hittable.rs:153,
+ *     src/aarect.rs:142-144, src/material.rs:146, src/constant_medium.rs:85,
+ *     src/bvh.rs:84, src/perlin.rs:21,30-32.  rand is not vendored, so these
+ *     shapes are restated from its published algorithm (parity unpinned).
+ *   - cgmath 0.18 vector semantics used throughout the reference
+ *     (dot = (x*x'+y*y')+z*z', normalize = v*(1/|v|), element-wise v/s).
+ *
+ * Philox4x32-10 is pinned by the Random123 known-answer vectors
+ * (tests/test_num_contract.py).  The elementary functions are pinned against
+ * glibc/mpmath within a stated ulp bound (same test file).
+ */
+#ifndef RT1W_NUM_H
+#define RT1W_NUM_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+/* ------------------------------------------------------------------ bits -- */
+
+RT_HD uint64_t rt_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+RT_HD double rt_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+
+#define RT_INF (__builtin_huge_val())
+#define RT_PI 3.14159265358979323846264338327950288
+
+RT_HD bool rt_isnan(double x) { return x != x; }
+RT_HD double rt_abs(double x) { return rt_u2d(rt_d2u(x) & 0x7FFFFFFFFFFFFFFFull); }
+/* Rust f64::min / f64::max: if one operand is NaN the other is returned. */
+RT_HD double rt_min(double a, double b) { return (a < b || rt_isnan(b)) ? a : b; }
+RT_HD double rt_max(double a, double b) { return (a > b || rt_isnan(b)) ? a : b; }
+RT_HD double rt_sqrt(double x) { return __builtin_sqrt(x); }
+/* floor without libm: |x| >= 2^52 is already integral. */
+RT_HD double rt_floor(double x) {
+    if (!(rt_abs(x) < 4503599627370496.0)) return x;
+    double t = (double)(int64_t)x; /* truncates toward zero */
+    return (t > x) ? t - 1.0 : t;
+}
+
+/* --------------------------------------------------------- Philox4x32-10 -- */
+
+struct RtPhiloxOut { uint32_t w0, w1, w2, w3; };
+
+RT_HD RtPhiloxOut rt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                   uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    RtPhiloxOut o; o.w0 = c0; o.w1 = c1; o.w2 = c2; o.w3 = c3; return o;
+}
+
+/* Word stream: block b of a stream is Philox(ctr=(b, c1, c2, c3), key=(k0,k1));
+ * words are consumed in order w0..w3.  A 64-bit draw takes an even-aligned word
+ * pair (low word first), so it never straddles a block. */
+#define RT_DOMAIN_RENDER 0x52454E44u /* "REND" */
+#define RT_DOMAIN_BUILD 0x424C4453u  /* "BLDS" */
+
+struct RtRng {
+    uint32_t k0, k1, c1, c2, c3;
+    uint32_t blk;  /* next block index to generate */
+    uint32_t idx;  /* next word in buf, 4 = empty */
+    uint32_t b0, b1, b2, b3;
+};
+
+RT_HD void rt_rng_refill(RtRng& r) {
+    RtPhiloxOut o = rt_philox4x32_10(r.blk, r.c1, r.c2, r.c3, r.k0, r.k1);
+    r.b0 = o.w0; r.b1 = o.w1; r.b2 = o.w2; r.b3 = o.w3;
+    r.blk += 1u; r.idx = 0u;
+}
+
+/* Stream of sample `sample` of the pixel whose reference seed is `pixel_seed`
+ * (= j*W+i, src/main.rs:964). */
+RT_HD RtRng rt_rng_pixel_sample(uint64_t pixel_seed, uint32_t sample, uint32_t global_seed) {
+    RtRng r;
+    r.k0 = (uint32_t)pixel_seed; r.k1 = (uint32_t)(pixel_seed >> 32);
+    r.c1 = sample; r.c2 = global_seed; r.c3 = RT_DOMAIN_RENDER;
+    r.blk = 0u; r.idx = 4u; r.b0 = r.b1 = r.b2 = r.b3 = 0u;
+    return r;
+}
+/* Sequential stream used by the one-shot scene build (replaces the reference's
+ * entropy-seeded `MyRng::from_entropy()`, src/main.rs:803). */
+RT_HD RtRng rt_rng_build(uint64_t build_seed) {
+    RtRng r;
+    r.k0 = (uint32_t)build_seed; r.k1 = (uint32_t)(build_seed >> 32);
+    r.c1 = 0u; r.c2 = 0u; r.c3 = RT_DOMAIN_BUILD;
+    r.blk = 0u; r.idx = 4u; r.b0 = r.b1 = r.b2 = r.b3 = 0u;
+    return r;
+}
+
+RT_HD uint32_t rt_next_u32(RtRng& r) {
+    if (r.idx >= 4u) rt_rng_refill(r);
+    uint32_t i = r.idx;
+    uint32_t w = (i == 0u) ? r.b0 : (i == 1u) ? r.b1 : (i == 2u) ? r.b2 : r.b3;
+    r.idx = i + 1u;
+    return w;
+}
+RT_HD uint64_t rt_next_u64(RtRng& r) {
+    uint32_t i = (r.idx + 1u) & ~1u;
+    if (i >= 4u) { rt_rng_refill(r); i = 0u; }
+    uint32_t lo = (i == 0u) ? r.b0 : r.b2;
+    uint32_t hi = (i == 0u) ? r.b1 : r.b3;
+    r.idx = i + 2u;
+    return ((uint64_t)hi << 32) | lo;
+}
+
+/* rand 0.8 `rng.gen::<f64>()`: 53 random bits scaled into [0,1). */
+RT_HD double rt_gen_f64(RtRng& r) {
+    return (double)(rt_next_u64(r) >> 11) * (1.0 / 9007199254740992.0);
+}
+/* rand 0.8 `rng.gen_range(low..high)` for f64 (UniformFloat::sample_single):
+ * 52 mantissa bits -> [1,2) -> minus 1 -> *scale + low, retry if >= high. */
+RT_HD double rt_gen_range(RtRng& r, double low, double high) {
+    double scale = high - low;
+    for (;;) {
+        double v12 = rt_u2d((rt_next_u64(r) >> 12) | 0x3FF0000000000000ull);
+        double res = (v12 - 1.0) * scale + low;
+        if (res < high) return res;
+    }
+}
+/* rand 0.8 `rng.gen::<bool>()`: sign bit of one u32. */
+RT_HD bool rt_gen_bool(RtRng& r) { return (int32_t)rt_next_u32(r) < 0; }
+/* rand 0.8 UniformInt<u32>::sample_single_inclusive(0, n-1) -- used by
+ * `slice.choose`, `shuffle` (gen_index) and `gen_range(0..=2)`:
+ * widening multiply with the conservative power-of-two zone. */
+RT_HD uint32_t rt_gen_below(RtRng& r, uint32_t n) {
+    uint32_t lz = (uint32_t)__builtin_clz(n);
+    uint32_t zone = (n << lz) - 1u;
+    for (;;) {
+        uint64_t m = (uint64_t)rt_next_u32(r) * n;
+        if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+    }
+}
+
+/* -------------------------------------------------- elementary functions -- */
+/* All of these are evaluated with + - * / only, in the order written, so the
+ * host and the device produce the same bits.  Accuracy targets (checked in
+ * tests/test_num_contract.py): sin/cos <= 1 ulp for |x| <= 1e5, atan2/acos/log
+ * <= 2 ulp. */
+
+/* kernel sin/cos on [-pi/4, pi/4] (fdlibm minimax polynomials, degree 13/14) */
+RT_HD double rt_ksin(double x, double y) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double v = z * x;
+    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+RT_HD double rt_kcos(double x, double y) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double hz = 0.5 * z;
+    double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+/* Cody-Waite reduction by pi/2 in three 33-bit pieces; exact products for
+ * |n| < 2^20, i.e. |x| < ~1.6e6 (accuracy degrades gradually beyond; callers
+ * return NaN for |x| >= 2^30, far outside any scene's coordinates, so the
+ * double->integer conversion below is always in range on both targets).
+ * Returns quadrant (0..3), remainder in (hi, lo). */
+RT_HD int rt_rem_pio2(double x, double& hi, double& lo) {
+    const double INVPIO2 = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632673412561417e+00;  /* 0x3FF921FB54400000 */
+    const double P1T = 6.07710050650619224932e-11;
+    const double P2 = 6.07710050630396597660e-11;  /* 0x3DD0B4611A600000 */
+    const double P2T = 2.02226624879595063154e-21;
+    const double P3 = 2.02226624871116645580e-21;  /* 0x3BA3198A2E000000 */
+    const double P3T = 8.47842766036889956997e-32;
+    double t = x * INVPIO2;
+    double fn = rt_floor(t + 0.5);
+    int n = (int)((int64_t)fn & 3);
+    /* three-stage subtraction, keeping a tail */
+    double r = x - fn * P1;
+    double w;
+    double y0;
+    /* second iteration (always; cost is small, accuracy uniform) */
+    double t2 = r;
+    w = fn * P2;
+    r = t2 - w;
+    w = fn * P2T - ((t2 - r) - w);
+    y0 = r - w;
+    /* third iteration */
+    double t3 = r;
+    double w3 = fn * P3;
+    r = t3 - w3;
+    w = fn * P3T - ((t3 - r) - w3);
+    y0 = r - w;
+    hi = y0;
+    lo = (r - y0) - w;
+    return n;
+}
+#define RT_TRIG_MAX 1073741824.0 /* 2^30 */
+RT_HD double rt_sin(double x) {
+    if (rt_abs(x) < 0.78539816339744830962) return rt_ksin(x, 0.0);
+    if (!(rt_abs(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
+    double hi, lo;
+    int n = rt_rem_pio2(x, hi, lo);
+    if (n == 0) return rt_ksin(hi, lo);
+    if (n == 1) return rt_kcos(hi, lo);
+    if (n == 2) return -rt_ksin(hi, lo);
+    return -rt_kcos(hi, lo);
+}
+RT_HD double rt_cos(double x) {
+    if (rt_abs(x) < 0.78539816339744830962) return rt_kcos(x, 0.0);
+    if (!(rt_abs(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
+    double hi, lo;
+    int n = rt_rem_pio2(x, hi, lo);
+    if (n == 0) return rt_kcos(hi, lo);
+    if (n == 1) return -rt_ksin(hi, lo);
+    if (n == 2) return -rt_kcos(hi, lo);
+    return rt_ksin(hi, lo);
+}
+/* sin and cos of one argument with one shared reduction (same values as above) */
+RT_HD void rt_sincos(double x, double& s, double& c) {
+    double hi = x, lo = 0.0;
+    int n = 0;
+    if (!(rt_abs(x) < RT_TRIG_MAX)) { s = c = rt_u2d(0x7FF8000000000000ull); return; }
+    if (!(rt_abs(x) < 0.78539816339744830962)) n = rt_rem_pio2(x, hi, lo);
+    double ks = rt_ksin(hi, lo), kc = rt_kcos(hi, lo);
+    s = (n == 0) ? ks : (n == 1) ? kc : (n == 2) ? -ks : -kc;
+    c = (n == 0) ? kc : (n == 1) ? -ks : (n == 2) ? -kc : ks;
+}
+RT_HD double rt_tan(double x) { double s, c; rt_sincos(x, s, c); return s / c; }
+
+/* atan for x >= 0 (fdlibm breakpoints 7/16, 11/16, 19/16, 39/16) */
+RT_HD double rt_atan_pos(double x) {
+    const double AT0 = 3.33333333333329318027e-01, AT1 = -1.99999999998764832476e-01,
+                 AT2 = 1.42857142725034663711e-01, AT3 = -1.11111104054623557880e-01,
+                 AT4 = 9.09088713343650656196e-02, AT5 = -7.69187620504482999495e-02,
+                 AT6 = 6.66107313738753120669e-02, AT7 = -5.83357013379057348645e-02,
+                 AT8 = 4.97687799461593236017e-02, AT9 = -3.65315727442169155270e-02,
+                 AT10 = 1.62858201153657823623e-02;
+    double hi, lo;
+    if (x < 0.4375) { hi = 0.0; lo = 0.0; }
+    else if (x < 0.6875) { hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17;
+                           x = (2.0 * x - 1.0) / (2.0 + x); }
+    else if (x < 1.1875) { hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17;
+                           x = (x - 1.0) / (x + 1.0); }
+    else if (x < 2.4375) { hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17;
+                           x = (x - 1.5) / (1.0 + 1.5 * x); }
+    else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17;
+           x = -1.0 / x; }
+    double z = x * x;
+    double w = z * z;
+    double s1 = z * (AT0 + w * (AT2 + w * (AT4 + w * (AT6 + w * (AT8 + w * AT10)))));
+    double s2 = w * (AT1 + w * (AT3 + w * (AT5 + w * (AT7 + w * AT9))));
+    if (hi == 0.0) return x - x * (s1 + s2);
+    return hi - ((x * (s1 + s2) - lo) - x);
+}
+RT_HD double rt_atan2(double y, double x) {
+    const double PI_LO = 1.2246467991473531772e-16;
+    if (rt_isnan(x) || rt_isnan(y)) return x + y;
+    bool yneg = (rt_d2u(y) >> 63) != 0, xneg = (rt_d2u(x) >> 63) != 0;
+    double ay = rt_abs(y), ax = rt_abs(x);
+    if (ay == 0.0) return xneg ? (yneg ? -RT_PI : RT_PI) : y;
+    if (ax == 0.0) return yneg ? -1.57079632679489655800e+00 : 1.57079632679489655800e+00;
+    double z;
+    if (ax == RT_INF && ay == RT_INF) z = 7.85398163397448278999e-01;
+    else if (ax == RT_INF) z = 0.0;
+    else if (ay == RT_INF) z = 1.57079632679489655800e+00;
+    else z = rt_atan_pos(ay / ax);
+    if (!xneg) return yneg ? -z : z;
+    double r = RT_PI - (z - PI_LO);
+    return yneg ? -r : r;
+}
+/* acos(x) = 2*atan2(sqrt(1-x), sqrt(1+x)) -- benign cancellation only */
+RT_HD double rt_acos(double x) {
+    if (!(x >= -1.0 && x <= 1.0)) return rt_u2d(0x7FF8000000000000ull);
+    return 2.0 * rt_atan2(rt_sqrt(1.0 - x), rt_sqrt(1.0 + x));
+}
+/* natural log (fdlibm): x = 2^k * (1+f), sqrt(1/2) < 1+f < sqrt(2) */
+RT_HD double rt_log(double x) {
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
+                 LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
+                 LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+                 LG7 = 1.479819860511658591e-01;
+    if (rt_isnan(x)) return x;
+    if (x < 0.0) return rt_u2d(0x7FF8000000000000ull);
+    if (x == 0.0) return -RT_INF;
+    if (x == RT_INF) return x;
+    int k = 0;
+    uint64_t u = rt_d2u(x);
+    if ((u >> 52) == 0) { x = x * 18014398509481984.0; k -= 54; u = rt_d2u(x); } /* subnormal */
+    k += (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = rt_u2d(u);
+    if (m > 1.41421356237309504880) { m = m * 0.5; k += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (LG2 + w * (LG4 + w * LG6));
+    double t2 = z * (LG1 + w * (LG3 + w * (LG5 + w * LG7)));
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)k;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+/* x.powf(5.0) of src/material.rs:124, as a fixed multiplication chain */
+RT_HD double rt_pow5(double x) { double x2 = x * x; return (x2 * x2) * x; }
+
+/* ------------------------------------------------------------------ vec3 -- */
+/* cgmath 0.18 semantics (un-vendored; restated): element-wise ops,
+ * dot = (x*x' + y*y') + z*z', normalize = v * (1/|v|). */
+
+struct RtV3 { double x, y, z; };
+
+RT_HD RtV3 rt_v3(double x, double y, double z) { RtV3 v; v.x = x; v.y = y; v.z = z; return v; }
+RT_HD RtV3 operator+(RtV3 a, RtV3 b) { return rt_v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD RtV3 operator-(RtV3 a, RtV3 b) { return rt_v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD RtV3 operator-(RtV3 a) { return rt_v3(-a.x, -a.y, -a.z); }
+RT_HD RtV3 operator*(RtV3 a, double s) { return rt_v3(a.x * s, a.y * s, a.z * s); }
+RT_HD RtV3 operator*(double s, RtV3 a) { return rt_v3(s * a.x, s * a.y, s * a.z); }
+RT_HD RtV3 operator/(RtV3 a, double s) { return rt_v3(a.x / s, a.y / s, a.z / s); }
+RT_HD RtV3 rt_mul(RtV3 a, RtV3 b) { return rt_v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD double rt_dot(RtV3 a, RtV3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_HD double rt_mag2(RtV3 a) { return rt_dot(a, a); }
+RT_HD double rt_mag(RtV3 a) { return rt_sqrt(rt_dot(a, a)); }
+RT_HD RtV3 rt_normalize(RtV3 a) { return a * (1.0 / rt_mag(a)); }
+RT_HD RtV3 rt_cross(RtV3 a, RtV3 b) {
+    return rt_v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_HD double rt_get(RtV3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+#endif /* RT1W_NUM_H */

@@ -1,0 +1,1245 @@
+/* oracle.cpp -- CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * A literal C++ restatement of hatoo/raytracing-1w's hot path (the per-pixel
+ * sample loop and the recursive `ray_color`) and of every trait implementor it
+ * calls, as an object graph with virtual dispatch -- the same shape as the Rust.
+ * Each function cites the reference lines it follows (paths under
+ * /root/reference/src).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this; librt1w never does.
+ *
+ * PARITY STATUS: "parity unpinned" against the Rust binary itself.  The
+ * reference is a Rust crate; this image has no rustc/cargo and the crates
+ * (rand 0.8.4, rand_chacha 0.3.1, cgmath 0.18.0, ...) are not vendored, so the
+ * reference cannot be compiled or run here, and it ships no tests, golden
+ * vectors or fixtures.  What pins this oracle instead:
+ *   (1) line-by-line correspondence with the cited source;
+ *   (2) hand-derived known answers for the leaf functions (tests/test_oracle_kat.py);
+ *   (3) a statistical match of the Cornell render against the only artefact of
+ *       the reference's own run, rest_of_your_life.png (tests/golden/);
+ *   (4) Random123 known-answer vectors for the generator.
+ *
+ * Deliberate, documented departures from the Rust (all mandated by the north
+ * star, none on the arithmetic of the path):
+ *   - RNG: Philox4x32-10 streams keyed (pixel seed j*W+i, sample index) instead of
+ *     one ChaCha12 stream per pixel (main.rs:964); rand 0.8 sampling shapes on top
+ *     (include/rt1w_num.h).
+ *   - sin/cos/acos/atan2/ln/tan/powf(5) are the deterministic functions of
+ *     include/rt1w_num.h (<= 2 ulp from libm) so that CPU and GPU agree bitwise.
+ *   - scene build RNG is seeded (build_seed) instead of `from_entropy` (main.rs:803).
+ *   - rayon is replaced by a std::thread pool over rows.
+ */
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+#include <algorithm>
+
+#include "rt1w_num.h"
+
+namespace orc {
+
+typedef double Float;
+typedef RtV3 V3;
+typedef RtRng MyRng;
+
+static thread_local uint64_t g_segments = 0;
+
+/* ray.rs:4-15 */
+struct Ray {
+    V3 origin, direction;
+    Float time;
+    V3 at(Float t) const { return origin + t * direction; }
+};
+
+struct Material;
+
+/* hittable.rs:10-47 */
+struct HitRecord {
+    V3 position, normal;
+    Float t, u, v;
+    bool front_face;
+    const Material* material;
+    static HitRecord make(V3 position, V3 outward_normal, Float t, Float u, Float v, const Ray& ray,
+                          const Material* material) {
+        HitRecord h;
+        bool front_face = rt_dot(ray.direction, outward_normal) < 0.0;
+        h.position = position;
+        h.normal = front_face ? outward_normal : -outward_normal;
+        h.t = t; h.u = u; h.v = v; h.front_face = front_face; h.material = material;
+        return h;
+    }
+};
+
+/* aabb.rs:7-52 */
+struct AABB {
+    V3 minimum, maximum;
+    bool hit(const Ray& ray, Float t_min, Float t_max) const {
+        for (int a = 0; a < 3; ++a) {
+            Float inv_d = 1.0 / rt_get(ray.direction, a);
+            Float t0 = (rt_get(minimum, a) - rt_get(ray.origin, a)) * inv_d;
+            Float t1 = (rt_get(maximum, a) - rt_get(ray.origin, a)) * inv_d;
+            if (inv_d < 0.0) std::swap(t0, t1);
+            t_min = t0 > t_min ? t0 : t_min;
+            t_max = t1 < t_max ? t1 : t_max;
+            if (t_max <= t_min) return false;
+        }
+        return true;
+    }
+};
+static AABB surrounding_box(const AABB& box0, const AABB& box1) {
+    AABB r;
+    r.minimum = rt_v3(rt_min(box0.minimum.x, box1.minimum.x), rt_min(box0.minimum.y, box1.minimum.y), rt_min(box0.minimum.z, box1.minimum.z));
+    r.maximum = rt_v3(rt_max(box0.maximum.x, box1.maximum.x), rt_max(box0.maximum.y, box1.maximum.y), rt_max(box0.maximum.z, box1.maximum.z));
+    return r;
+}
+
+/* hittable.rs:63-72 */
+struct Hittable {
+    virtual ~Hittable() {}
+    virtual bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const = 0;
+    virtual bool bounding_box(Float time0, Float time1, AABB& out) const = 0;
+    virtual Float pdf_value(V3, V3, MyRng&) const { return 0.0; }
+    virtual V3 random(V3, MyRng&) const { return rt_v3(1.0, 0.0, 0.0); }
+};
+typedef std::unique_ptr<Hittable> HBox;
+
+/* ---- math.rs ---- */
+static V3 random_in_unit_sphere(MyRng& rng) { /* math.rs:6-18 */
+    for (;;) {
+        Float x = rt_gen_range(rng, -1.0, 1.0);
+        Float y = rt_gen_range(rng, -1.0, 1.0);
+        Float z = rt_gen_range(rng, -1.0, 1.0);
+        V3 v = rt_v3(x, y, z);
+        if (rt_mag2(v) < 1.0) return v;
+    }
+}
+static V3 random_in_unit_disk(MyRng& rng) { /* math.rs:30-37 */
+    for (;;) {
+        Float x = rt_gen_range(rng, -1.0, 1.0);
+        Float y = rt_gen_range(rng, -1.0, 1.0);
+        V3 p = rt_v3(x, y, 0.0);
+        if (rt_mag2(p) < 1.0) return p;
+    }
+}
+static V3 random_cosine_direction(MyRng& rng) { /* math.rs:39-49 */
+    Float r1 = rt_gen_f64(rng);
+    Float r2 = rt_gen_f64(rng);
+    Float z = rt_sqrt(1.0 - r2);
+    Float phi = 2.0 * RT_PI * r1;
+    Float x = rt_cos(phi) * rt_sqrt(r2);
+    Float y = rt_sin(phi) * rt_sqrt(r2);
+    return rt_v3(x, y, z);
+}
+static V3 random_to_sphere(Float radius, Float distance_squared, MyRng& rng) { /* math.rs:51-65 */
+    Float r1 = rt_gen_f64(rng);
+    Float r2 = rt_gen_f64(rng);
+    Float z = 1.0 + r2 * (rt_sqrt(1.0 - radius * radius / distance_squared) - 1.0);
+    Float phi = 2.0 * RT_PI * r1;
+    Float x = rt_cos(phi) * rt_sqrt(1.0 - z * z);
+    Float y = rt_sin(phi) * rt_sqrt(1.0 - z * z);
+    return rt_v3(x, y, z);
+}
+static void sphere_uv(V3 point, Float& u, Float& v) { /* math.rs:67-71 */
+    Float theta = rt_acos(-point.y);
+    Float phi = rt_atan2(-point.z, point.x) + RT_PI;
+    u = phi / (2.0 * RT_PI);
+    v = theta / RT_PI;
+}
+
+/* onb.rs:5-28 */
+struct Onb {
+    V3 u, v, w;
+    static Onb from_w(V3 n) {
+        Onb o;
+        o.w = rt_normalize(n);
+        V3 a = rt_abs(o.w.x) > 0.9 ? rt_v3(0.0, 1.0, 0.0) : rt_v3(1.0, 0.0, 0.0);
+        o.v = rt_normalize(rt_cross(o.w, a));
+        o.u = rt_cross(o.w, o.v);
+        return o;
+    }
+    V3 local(V3 a) const { return u * a.x + v * a.y + w * a.z; }
+};
+
+/* ---- texture.rs / perlin.rs ---- */
+struct Texture {
+    virtual ~Texture() {}
+    virtual V3 value(Float u, Float v, V3 point) const = 0;
+};
+typedef std::shared_ptr<Texture> TexPtr;
+
+struct SolidColor : Texture { /* texture.rs:40-44 */
+    V3 color_value;
+    explicit SolidColor(V3 c) : color_value(c) {}
+    V3 value(Float, Float, V3) const override { return color_value; }
+};
+struct CheckerTexture : Texture { /* texture.rs:46-55 */
+    TexPtr odd, even;
+    CheckerTexture(TexPtr o, TexPtr e) : odd(o), even(e) {}
+    V3 value(Float u, Float v, V3 point) const override {
+        Float sines = rt_sin(10.0 * point.x) * rt_sin(10.0 * point.y) * rt_sin(10.0 * point.z);
+        if (sines < 0.0) return odd->value(u, v, point);
+        return even->value(u, v, point);
+    }
+};
+struct Perlin { /* perlin.rs:8-106, POINT_COUNT = 256 */
+    V3 ranvec[256];
+    size_t perm_x[256], perm_y[256], perm_z[256];
+    static void generate_perm(MyRng& rng, size_t* p) { /* perlin.rs:16-23 */
+        for (size_t i = 0; i < 256; ++i) p[i] = i;
+        for (size_t i = 255; i >= 1; --i) { /* SliceRandom::shuffle */
+            size_t j = rt_gen_below(rng, (uint32_t)(i + 1));
+            std::swap(p[i], p[j]);
+        }
+    }
+    explicit Perlin(MyRng& rng) { /* perlin.rs:25-43 */
+        for (int i = 0; i < 256; ++i) {
+            Float x = rt_gen_range(rng, -1.0, 1.0);
+            Float y = rt_gen_range(rng, -1.0, 1.0);
+            Float z = rt_gen_range(rng, -1.0, 1.0);
+            ranvec[i] = rt_normalize(rt_v3(x, y, z));
+        }
+        generate_perm(rng, perm_x);
+        generate_perm(rng, perm_y);
+        generate_perm(rng, perm_z);
+    }
+    static int64_t as_isize(Float f) { /* saturating `as isize` */
+        if (f != f) return 0;
+        if (f >= 9.2e18) return INT64_MAX;
+        if (f <= -9.2e18) return INT64_MIN;
+        return (int64_t)f;
+    }
+    Float noise(V3 p) const { /* perlin.rs:46-72 */
+        Float u = p.x - rt_floor(p.x);
+        Float v = p.y - rt_floor(p.y);
+        Float w = p.z - rt_floor(p.z);
+        int64_t i = as_isize(rt_floor(p.x));
+        int64_t j = as_isize(rt_floor(p.y));
+        int64_t k = as_isize(rt_floor(p.z));
+        V3 c[2][2][2];
+        for (int di = 0; di < 2; ++di)
+            for (int dj = 0; dj < 2; ++dj)
+                for (int dk = 0; dk < 2; ++dk) {
+                    size_t ii = (size_t)(((uint64_t)i + (uint64_t)di) & 255u);
+                    size_t jj = (size_t)(((uint64_t)j + (uint64_t)dj) & 255u);
+                    size_t kk = (size_t)(((uint64_t)k + (uint64_t)dk) & 255u);
+                    c[di][dj][dk] = ranvec[perm_x[ii] ^ perm_y[jj] ^ perm_z[kk]];
+                }
+        return perlin_interp(c, u, v, w);
+    }
+    Float turb(V3 p, int depth) const { /* perlin.rs:74-86 */
+        Float accum = 0.0;
+        V3 temp_p = p;
+        Float weight = 1.0;
+        for (int i = 0; i < depth; ++i) {
+            accum += weight * noise(temp_p);
+            weight *= 0.5;
+            temp_p = temp_p * 2.0;
+        }
+        return rt_abs(accum);
+    }
+    static Float perlin_interp(V3 c[2][2][2], Float u, Float v, Float w) { /* perlin.rs:88-106 */
+        Float uu = u * u * (3.0 - 2.0 * u);
+        Float vv = v * v * (3.0 - 2.0 * v);
+        Float ww = w * w * (3.0 - 2.0 * w);
+        Float accum = 0.0;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    V3 weight_v = rt_v3(u - (Float)i, v - (Float)j, w - (Float)k);
+                    accum += ((Float)i * uu + (Float)(1 - i) * (1.0 - uu)) * ((Float)j * vv + (Float)(1 - j) * (1.0 - vv)) *
+                             ((Float)k * ww + (Float)(1 - k) * (1.0 - ww)) * rt_dot(c[i][j][k], weight_v);
+                }
+        return accum;
+    }
+};
+struct NoiseTexture : Texture { /* texture.rs:24-38,57-65 */
+    Perlin perlin;
+    Float scale;
+    NoiseTexture(Float s, MyRng& rng) : perlin(rng), scale(s) {}
+    V3 value(Float, Float, V3 point) const override {
+        return rt_v3(1.0, 1.0, 1.0) * 0.5 * (1.0 + rt_sin(scale * point.z + 10.0 * perlin.turb(point, 7)));
+    }
+};
+struct ImageTexture : Texture { /* impl Texture for DynamicImage texture.rs:67-89 */
+    std::vector<uint8_t> rgb;
+    uint32_t width, height;
+    ImageTexture(const uint8_t* p, uint32_t w, uint32_t h) : rgb(p, p + (size_t)w * h * 3), width(w), height(h) {}
+    static uint32_t as_u32(Float x) { if (!(x > 0.0)) return 0u; if (x >= 4294967295.0) return 4294967295u; return (uint32_t)x; }
+    V3 value(Float u, Float v, V3) const override {
+        u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+        v = 1.0 - (v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v));
+        uint32_t i = as_u32(u * (Float)width);
+        uint32_t j = as_u32(v * (Float)height);
+        i = std::min(i, width - 1);
+        j = std::min(j, height - 1);
+        const uint8_t* pixel = &rgb[((size_t)j * width + i) * 3];
+        const Float COLOR_SCALE = 1.0 / 255.0;
+        return rt_v3((Float)pixel[0] * COLOR_SCALE, (Float)pixel[1] * COLOR_SCALE, (Float)pixel[2] * COLOR_SCALE);
+    }
+};
+
+/* ---- pdf.rs ---- */
+struct Pdf {
+    virtual ~Pdf() {}
+    virtual Float value(V3 direction, MyRng& rng) const = 0;
+    virtual V3 generate(MyRng& rng) const = 0;
+};
+struct CosinePdf : Pdf { /* pdf.rs:12-14,36-45 */
+    Onb uvw;
+    explicit CosinePdf(Onb o) : uvw(o) {}
+    Float value(V3 direction, MyRng&) const override {
+        Float cosine = rt_dot(rt_normalize(direction), uvw.w);
+        return rt_max(cosine / RT_PI, 0.0);
+    }
+    V3 generate(MyRng& rng) const override { return uvw.local(random_cosine_direction(rng)); }
+};
+struct HittablePdf : Pdf { /* pdf.rs:16-19,47-55 */
+    V3 o;
+    const Hittable* hittable;
+    HittablePdf(const Hittable* h, V3 origin) : o(origin), hittable(h) {}
+    Float value(V3 direction, MyRng& rng) const override { return hittable->pdf_value(o, direction, rng); }
+    V3 generate(MyRng& rng) const override { return hittable->random(o, rng); }
+};
+struct MixturePdf : Pdf { /* pdf.rs:21-24,57-69 */
+    const Pdf* p0;
+    const Pdf* p1;
+    MixturePdf(const Pdf* a, const Pdf* b) : p0(a), p1(b) {}
+    Float value(V3 direction, MyRng& rng) const override {
+        Float a = p0->value(direction, rng);
+        Float b = p1->value(direction, rng);
+        return 0.5 * a + 0.5 * b;
+    }
+    V3 generate(MyRng& rng) const override {
+        if (rt_gen_bool(rng)) return p0->generate(rng);
+        return p1->generate(rng);
+    }
+};
+
+/* ---- material.rs ---- */
+struct Scatter { /* material.rs:15-23 */
+    bool is_specular = false;       /* ScatterKind::Spacular(Ray) */
+    Ray specular{};
+    std::unique_ptr<Pdf> pdf;       /* ScatterKind::Pdf(Box<dyn Pdf>) */
+    V3 attenuation{};
+};
+struct Material { /* material.rs:25-50 */
+    virtual ~Material() {}
+    virtual bool scatter(const Ray&, const HitRecord&, MyRng&, Scatter&) const { return false; }
+    virtual Float scattering_pdf(const Ray&, const HitRecord&, const Ray&, MyRng&) const { return 0.0; }
+    virtual V3 emitted(const Ray&, const HitRecord&, Float, Float, V3) const { return rt_v3(0.0, 0.0, 0.0); }
+};
+typedef std::shared_ptr<Material> MatPtr;
+struct NullMaterial : Material {}; /* impl Material for () material.rs:68 */
+
+struct Lambertian : Material { /* material.rs:70-92 */
+    TexPtr albedo;
+    explicit Lambertian(TexPtr a) : albedo(a) {}
+    bool scatter(const Ray&, const HitRecord& hit_record, MyRng&, Scatter& out) const override {
+        out.attenuation = albedo->value(hit_record.u, hit_record.v, hit_record.position);
+        out.is_specular = false;
+        out.pdf.reset(new CosinePdf(Onb::from_w(hit_record.normal)));
+        return true;
+    }
+    Float scattering_pdf(const Ray&, const HitRecord& hit_record, const Ray& ray_scatterd, MyRng&) const override {
+        Float cosine = rt_dot(hit_record.normal, rt_normalize(ray_scatterd.direction));
+        return rt_max(cosine / RT_PI, 0.0);
+    }
+};
+static V3 reflect(V3 v, V3 n) { return v - 2.0 * rt_dot(v, n) * n; } /* material.rs:94-96 */
+struct Metal : Material { /* material.rs:98-112 */
+    V3 albedo;
+    Float fuzz;
+    Metal(V3 a, Float f) : albedo(a), fuzz(f) {}
+    bool scatter(const Ray& ray, const HitRecord& hit_record, MyRng& rng, Scatter& out) const override {
+        V3 reflected = reflect(rt_normalize(ray.direction), hit_record.normal);
+        out.is_specular = true;
+        out.specular.origin = hit_record.position;
+        out.specular.direction = reflected + fuzz * random_in_unit_sphere(rng);
+        out.specular.time = ray.time;
+        out.attenuation = albedo;
+        return true;
+    }
+};
+static V3 refract(V3 uv, V3 n, Float etai_over_etat) { /* material.rs:114-119 */
+    Float cos_theta = rt_min(rt_dot(-uv, n), 1.0);
+    V3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    V3 r_out_parallel = -rt_sqrt(rt_abs(1.0 - rt_mag2(r_out_perp))) * n;
+    return r_out_perp + r_out_parallel;
+}
+static Float reflectance(Float cosine, Float ref_idx) { /* material.rs:121-125 */
+    Float r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0 - r0) * rt_pow5(1.0 - cosine);
+}
+struct Dielectric : Material { /* material.rs:127-161 */
+    Float ir;
+    explicit Dielectric(Float i) : ir(i) {}
+    bool scatter(const Ray& ray, const HitRecord& hit_record, MyRng& rng, Scatter& out) const override {
+        Float refraction_ratio = hit_record.front_face ? 1.0 / ir : ir;
+        V3 unit_direction = rt_normalize(ray.direction);
+        Float cos_theta = rt_min(rt_dot(-unit_direction, hit_record.normal), 1.0);
+        Float sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        V3 direction;
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rt_gen_f64(rng))
+            direction = reflect(unit_direction, hit_record.normal);
+        else
+            direction = refract(unit_direction, hit_record.normal, refraction_ratio);
+        out.attenuation = rt_v3(1.0, 1.0, 1.0);
+        out.is_specular = true;
+        out.specular.origin = hit_record.position;
+        out.specular.direction = direction;
+        out.specular.time = ray.time;
+        return true;
+    }
+};
+struct DiffuseLight : Material { /* material.rs:163-182 */
+    TexPtr emit;
+    explicit DiffuseLight(TexPtr e) : emit(e) {}
+    V3 emitted(const Ray&, const HitRecord& hit_record, Float u, Float v, V3 p) const override {
+        if (hit_record.front_face) return emit->value(u, v, p);
+        return rt_v3(0.0, 0.0, 0.0);
+    }
+};
+struct Isotropic : Material { /* constant_medium.rs:31-51 */
+    TexPtr albedo;
+    explicit Isotropic(TexPtr a) : albedo(a) {}
+    bool scatter(const Ray& ray, const HitRecord& hit_record, MyRng& rng, Scatter& out) const override {
+        out.attenuation = albedo->value(hit_record.u, hit_record.v, hit_record.position);
+        out.is_specular = true;
+        out.specular.origin = hit_record.position;
+        out.specular.direction = random_in_unit_sphere(rng);
+        out.specular.time = ray.time;
+        return true;
+    }
+};
+
+/* ---- sphere.rs ---- */
+struct Sphere : Hittable {
+    V3 center; Float radius; MatPtr material;
+    Sphere(V3 c, Float r, MatPtr m) : center(c), radius(r), material(m) {}
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng&, HitRecord& out) const override { /* sphere.rs:24-63 */
+        V3 oc = ray.origin - center;
+        Float a = rt_mag2(ray.direction);
+        Float half_b = rt_dot(oc, ray.direction);
+        Float c = rt_mag2(oc) - radius * radius;
+        Float discriminant = half_b * half_b - a * c;
+        if (discriminant < 0.0) return false;
+        Float sqrtd = rt_sqrt(discriminant);
+        Float root = (-half_b - sqrtd) / a;
+        if (root < t_min || t_max < root) {
+            root = (-half_b + sqrtd) / a;
+            if (root < t_min || t_max < root) return false;
+        }
+        V3 position = ray.at(root);
+        V3 outward_normal = (position - center) / radius;
+        Float u, v;
+        sphere_uv(outward_normal, u, v);
+        out = HitRecord::make(position, outward_normal, root, u, v, ray, material.get());
+        return true;
+    }
+    bool bounding_box(Float, Float, AABB& out) const override { /* sphere.rs:65-70 */
+        out.minimum = center - rt_v3(radius, radius, radius);
+        out.maximum = center + rt_v3(radius, radius, radius);
+        return true;
+    }
+    Float pdf_value(V3 o, V3 v, MyRng& rng) const override { /* sphere.rs:72-90 */
+        HitRecord rec;
+        Ray r{o, v, 0.0};
+        if (!hit(r, 0.001, RT_INF, rng, rec)) return 0.0;
+        Float cos_theta_max = rt_sqrt(1.0 - radius * radius / rt_mag2(center - o));
+        Float solid_angle = 2.0 * RT_PI * (1.0 - cos_theta_max);
+        return 1.0 / solid_angle;
+    }
+    V3 random(V3 o, MyRng& rng) const override { /* sphere.rs:92-99 */
+        V3 direction = center - o;
+        Float distance_squared = rt_mag2(direction);
+        Onb uvw = Onb::from_w(direction);
+        return uvw.local(random_to_sphere(radius, distance_squared, rng));
+    }
+};
+
+/* ---- moving_sphere.rs ---- */
+struct MovingSphere : Hittable {
+    V3 center0, center1; Float time0, time1, radius; MatPtr material;
+    MovingSphere(V3 c0, V3 c1, Float t0, Float t1, Float r, MatPtr m) : center0(c0), center1(c1), time0(t0), time1(t1), radius(r), material(m) {}
+    V3 center(Float time) const { return center0 + ((time - time0) / (time1 - time0)) * (center1 - center0); } /* :23-26 */
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng&, HitRecord& out) const override { /* :31-70 */
+        V3 oc = ray.origin - center(ray.time);
+        Float a = rt_mag2(ray.direction);
+        Float half_b = rt_dot(oc, ray.direction);
+        Float c = rt_mag2(oc) - radius * radius;
+        Float discriminant = half_b * half_b - a * c;
+        if (discriminant < 0.0) return false;
+        Float sqrtd = rt_sqrt(discriminant);
+        Float root = (-half_b - sqrtd) / a;
+        if (root < t_min || t_max < root) {
+            root = (-half_b + sqrtd) / a;
+            if (root < t_min || t_max < root) return false;
+        }
+        V3 position = ray.at(root);
+        V3 outward_normal = (position - center(ray.time)) / radius;
+        Float u, v;
+        sphere_uv(outward_normal, u, v);
+        out = HitRecord::make(position, outward_normal, root, u, v, ray, material.get());
+        return true;
+    }
+    bool bounding_box(Float t0, Float t1, AABB& out) const override { /* :72-84 */
+        V3 r = rt_v3(radius, radius, radius);
+        AABB box0{center(t0) - r, center(t0) + r};
+        AABB box1{center(t1) - r, center(t1) + r};
+        out = surrounding_box(box0, box1);
+        return true;
+    }
+};
+
+/* ---- aarect.rs ---- */
+struct XYRect : Hittable {
+    Float x0, x1, y0, y1, k; MatPtr material;
+    XYRect(Float a, Float b, Float c, Float d, Float kk, MatPtr m) : x0(a), x1(b), y0(c), y1(d), k(kk), material(m) {}
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng&, HitRecord& out) const override { /* aarect.rs:46-72 */
+        Float t = (k - ray.origin.z) / ray.direction.z;
+        if (t < t_min || t > t_max) return false;
+        Float x = ray.origin.x + t * ray.direction.x;
+        Float y = ray.origin.y + t * ray.direction.y;
+        if (x < x0 || x > x1 || y < y0 || y > y1) return false;
+        Float u = (x - x0) / (x1 - x0);
+        Float v = (y - y0) / (y1 - y0);
+        out = HitRecord::make(ray.at(t), rt_v3(0.0, 0.0, 1.0), t, u, v, ray, material.get());
+        return true;
+    }
+    bool bounding_box(Float, Float, AABB& out) const override { /* :74-79 */
+        out.minimum = rt_v3(x0, y0, k - 0.0001); out.maximum = rt_v3(x1, y1, k + 0.0001); return true;
+    }
+};
+struct XZRect : Hittable {
+    Float x0, x1, z0, z1, k; MatPtr material;
+    XZRect(Float a, Float b, Float c, Float d, Float kk, MatPtr m) : x0(a), x1(b), z0(c), z1(d), k(kk), material(m) {}
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng&, HitRecord& out) const override { /* aarect.rs:84-110 */
+        Float t = (k - ray.origin.y) / ray.direction.y;
+        if (t < t_min || t > t_max) return false;
+        Float x = ray.origin.x + t * ray.direction.x;
+        Float z = ray.origin.z + t * ray.direction.z;
+        if (x < x0 || x > x1 || z < z0 || z > z1) return false;
+        Float u = (x - x0) / (x1 - x0);
+        Float v = (z - z0) / (z1 - z0);
+        out = HitRecord::make(ray.at(t), rt_v3(0.0, 1.0, 0.0), t, u, v, ray, material.get());
+        return true;
+    }
+    bool bounding_box(Float, Float, AABB& out) const override { /* :112-117 */
+        out.minimum = rt_v3(x0, k - 0.0001, z0); out.maximum = rt_v3(x1, k + 0.0001, z1); return true;
+    }
+    Float pdf_value(V3 origin, V3 v, MyRng& rng) const override { /* :119-138 */
+        HitRecord hit_record;
+        Ray r{origin, v, 0.0};
+        if (!hit(r, 0.001, RT_INF, rng, hit_record)) return 0.0;
+        Float area = (x1 - x0) * (z1 - z0);
+        Float distance_squared = hit_record.t * hit_record.t * rt_mag2(v);
+        Float cosine = rt_abs(rt_dot(v, hit_record.normal) / rt_mag(v));
+        return distance_squared / (cosine * area);
+    }
+    V3 random(V3 origin, MyRng& rng) const override { /* :140-147 */
+        Float x = rt_gen_range(rng, x0, x1);
+        Float z = rt_gen_range(rng, z0, z1);
+        V3 random_point = rt_v3(x, k, z);
+        return random_point - origin;
+    }
+};
+struct YZRect : Hittable {
+    Float y0, y1, z0, z1, k; MatPtr material;
+    YZRect(Float a, Float b, Float c, Float d, Float kk, MatPtr m) : y0(a), y1(b), z0(c), z1(d), k(kk), material(m) {}
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng&, HitRecord& out) const override { /* aarect.rs:152-178 */
+        Float t = (k - ray.origin.x) / ray.direction.x;
+        if (t < t_min || t > t_max) return false;
+        Float y = ray.origin.y + t * ray.direction.y;
+        Float z = ray.origin.z + t * ray.direction.z;
+        if (y < y0 || y > y1 || z < z0 || z > z1) return false;
+        Float u = (y - y0) / (y1 - y0);
+        Float v = (z - z0) / (z1 - z0);
+        out = HitRecord::make(ray.at(t), rt_v3(1.0, 0.0, 0.0), t, u, v, ray, material.get());
+        return true;
+    }
+    bool bounding_box(Float, Float, AABB& out) const override { /* :180-185 */
+        out.minimum = rt_v3(k - 0.0001, y0, z0); out.maximum = rt_v3(k + 0.0001, y1, z1); return true;
+    }
+};
+
+/* ---- bvh.rs ---- */
+static uint64_t float_ord_key(Float x) { /* float-ord 0.3.1: total order on bits */
+    uint64_t u = rt_d2u(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+struct BVHNode : Hittable {
+    HBox left, right; /* BVHChild::One(obj) -> left only */
+    AABB aabb;
+    bool bounding_box(Float, Float, AABB& out) const override { out = aabb; return true; } /* :21-23 */
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override { /* :25-50 */
+        if (!aabb.hit(ray, t_min, t_max)) return false;
+        if (!right) return left->hit(ray, t_min, t_max, rng, out);
+        HitRecord hit_left;
+        if (left->hit(ray, t_min, t_max, rng, hit_left)) {
+            HitRecord hit_right;
+            if (right->hit(ray, t_min, hit_left.t, rng, hit_right)) out = hit_right;
+            else out = hit_left;
+            return true;
+        }
+        return right->hit(ray, t_min, t_max, rng, out);
+    }
+    /* BVHNode::new bvh.rs:54-103; throws std::string on the reference's panics */
+    static std::unique_ptr<BVHNode> make(std::vector<HBox> objects, Float time0, Float time1, MyRng& rng) {
+        std::unique_ptr<BVHNode> n(new BVHNode());
+        size_t len = objects.size();
+        if (len == 0) throw std::string("objects mut not be empty");
+        if (len == 1) {
+            HBox obj = std::move(objects.back()); objects.pop_back();
+            if (!obj->bounding_box(time0, time1, n->aabb)) throw std::string("Bounding Box is required");
+            n->left = std::move(obj);
+        } else if (len == 2) {
+            HBox left = std::move(objects.back()); objects.pop_back();
+            HBox right = std::move(objects.back()); objects.pop_back();
+            AABB lb, rb;
+            if (!left->bounding_box(time0, time1, lb) || !right->bounding_box(time0, time1, rb)) throw std::string("unwrap on None");
+            n->aabb = surrounding_box(lb, rb);
+            n->left = std::move(left); n->right = std::move(right);
+        } else {
+            uint32_t axis = rt_gen_below(rng, 3u); /* rng.gen_range(0..=2) */
+            std::vector<std::pair<uint64_t, size_t>> keyed;
+            for (size_t i = 0; i < len; ++i) {
+                AABB b;
+                if (!objects[i]->bounding_box(time0, time1, b)) throw std::string("unwrap on None");
+                keyed.push_back({float_ord_key(rt_get(b.minimum, (int)axis)), i});
+            }
+            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, size_t>& a, const std::pair<uint64_t, size_t>& b) { return a.first < b.first; });
+            std::vector<HBox> l, r;
+            for (size_t i = 0; i < len; ++i) (i < len / 2 ? l : r).push_back(std::move(objects[keyed[i].second]));
+            std::unique_ptr<BVHNode> ln = make(std::move(l), time0, time1, rng);
+            std::unique_ptr<BVHNode> rn = make(std::move(r), time0, time1, rng);
+            n->aabb = surrounding_box(ln->aabb, rn->aabb);
+            n->left = std::move(ln); n->right = std::move(rn);
+        }
+        return n;
+    }
+};
+
+/* ---- aabox.rs ---- */
+struct AABox : Hittable {
+    V3 box_min, box_max;
+    std::unique_ptr<BVHNode> sides;
+    AABox(V3 p0, V3 p1, MatPtr material, MyRng& rng) : box_min(p0), box_max(p1) { /* aabox.rs:22-84 */
+        std::vector<HBox> s;
+        s.emplace_back(new XYRect(p0.x, p1.x, p0.y, p1.y, p1.z, material));
+        s.emplace_back(new XYRect(p0.x, p1.x, p0.y, p1.y, p0.z, material));
+        s.emplace_back(new XZRect(p0.x, p1.x, p0.z, p1.z, p1.y, material));
+        s.emplace_back(new XZRect(p0.x, p1.x, p0.z, p1.z, p0.y, material));
+        s.emplace_back(new YZRect(p0.y, p1.y, p0.z, p1.z, p1.x, material));
+        s.emplace_back(new YZRect(p0.y, p1.y, p0.z, p1.z, p0.x, material));
+        sides = BVHNode::make(std::move(s), 0.0, 1.0, rng);
+    }
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override { return sides->hit(ray, t_min, t_max, rng, out); } /* :88-96 */
+    bool bounding_box(Float, Float, AABB& out) const override { out.minimum = box_min; out.maximum = box_max; return true; } /* :98-103 */
+};
+
+/* ---- hittable.rs wrappers ---- */
+struct Translate : Hittable { /* hittable.rs:49-52,205-234 */
+    HBox hittable; V3 offset;
+    Translate(HBox h, V3 o) : hittable(std::move(h)), offset(o) {}
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override {
+        Ray moved{ray.origin - offset, ray.direction, ray.time};
+        HitRecord hr;
+        if (!hittable->hit(moved, t_min, t_max, rng, hr)) return false;
+        out = HitRecord::make(hr.position + offset, hr.normal, hr.t, hr.u, hr.v, moved, hr.material);
+        return true;
+    }
+    bool bounding_box(Float t0, Float t1, AABB& out) const override {
+        AABB b;
+        if (!hittable->bounding_box(t0, t1, b)) return false;
+        out.minimum = b.minimum + offset; out.maximum = b.maximum + offset;
+        return true;
+    }
+};
+struct RotateY : Hittable { /* hittable.rs:54-59,157-203,236-284 */
+    HBox hittable; Float sin_theta, cos_theta; bool has_aabb; AABB aabb;
+    RotateY(HBox h, Float time0, Float time1, Float angle_deg) : hittable(std::move(h)) {
+        Float radians = angle_deg * (RT_PI / 180.0);
+        rt_sincos(radians, sin_theta, cos_theta);
+        AABB bbox;
+        has_aabb = hittable->bounding_box(time0, time1, bbox);
+        if (has_aabb) {
+            V3 mn = rt_v3(RT_INF, RT_INF, RT_INF), mx = rt_v3(-RT_INF, -RT_INF, -RT_INF);
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j)
+                    for (int k = 0; k < 2; ++k) {
+                        Float x = (Float)i * bbox.maximum.x + (1.0 - (Float)i) * bbox.minimum.x;
+                        Float y = (Float)j * bbox.maximum.y + (1.0 - (Float)j) * bbox.minimum.y;
+                        Float z = (Float)k * bbox.maximum.z + (1.0 - (Float)k) * bbox.minimum.z;
+                        Float newx = cos_theta * x + sin_theta * z;
+                        Float newz = -sin_theta * x + cos_theta * z;
+                        V3 tester = rt_v3(newx, y, newz);
+                        mn = rt_v3(rt_min(mn.x, tester.x), rt_min(mn.y, tester.y), rt_min(mn.z, tester.z));
+                        mx = rt_v3(rt_max(mx.x, tester.x), rt_max(mx.y, tester.y), rt_max(mx.z, tester.z));
+                    }
+            aabb.minimum = mn; aabb.maximum = mx;
+        }
+    }
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override {
+        V3 origin = ray.origin, direction = ray.direction;
+        origin.x = cos_theta * ray.origin.x - sin_theta * ray.origin.z;
+        origin.z = sin_theta * ray.origin.x + cos_theta * ray.origin.z;
+        direction.x = cos_theta * ray.direction.x - sin_theta * ray.direction.z;
+        direction.z = sin_theta * ray.direction.x + cos_theta * ray.direction.z;
+        Ray rotated_r{origin, direction, ray.time};
+        HitRecord hr;
+        if (!hittable->hit(rotated_r, t_min, t_max, rng, hr)) return false;
+        V3 p = hr.position, normal = hr.normal;
+        p.x = cos_theta * hr.position.x + sin_theta * hr.position.z;
+        p.z = -sin_theta * hr.position.x + cos_theta * hr.position.z;
+        normal.x = cos_theta * hr.normal.x + sin_theta * hr.normal.z;
+        normal.z = -sin_theta * hr.normal.x + cos_theta * hr.normal.z;
+        out = HitRecord::make(p, normal, hr.t, hr.u, hr.v, rotated_r, hr.material);
+        return true;
+    }
+    bool bounding_box(Float, Float, AABB& out) const override { if (!has_aabb) return false; out = aabb; return true; }
+};
+struct FlipFace : Hittable { /* hittable.rs:61,286-297 */
+    HBox inner;
+    explicit FlipFace(HBox h) : inner(std::move(h)) {}
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override {
+        if (!inner->hit(ray, t_min, t_max, rng, out)) return false;
+        out.front_face = !out.front_face;
+        return true;
+    }
+    bool bounding_box(Float t0, Float t1, AABB& out) const override { return inner->bounding_box(t0, t1, out); }
+};
+/* impl Hittable for [T] hittable.rs:110-155 (the lights list) */
+struct HittableList : Hittable {
+    std::vector<HBox> items;
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override {
+        bool any = false;
+        Float closest_so_far = t_max;
+        for (const HBox& h : items) {
+            HitRecord r;
+            if (h->hit(ray, t_min, closest_so_far, rng, r)) { closest_so_far = r.t; out = r; any = true; }
+        }
+        return any;
+    }
+    bool bounding_box(Float t0, Float t1, AABB& out) const override {
+        bool have = false;
+        for (const HBox& h : items) {
+            AABB b0;
+            if (!h->bounding_box(t0, t1, b0)) return false;
+            out = have ? surrounding_box(out, b0) : b0;
+            have = true;
+        }
+        return have;
+    }
+    Float pdf_value(V3 o, V3 v, MyRng& rng) const override {
+        Float weight = 1.0 / (Float)items.size();
+        Float sum = 0.0;
+        for (const HBox& h : items) sum = sum + weight * h->pdf_value(o, v, rng);
+        return sum;
+    }
+    V3 random(V3 o, MyRng& rng) const override {
+        size_t i = rt_gen_below(rng, (uint32_t)items.size()); /* self.choose(rng).unwrap() */
+        return items[i]->random(o, rng);
+    }
+};
+
+/* ---- constant_medium.rs ---- */
+struct ConstantMedium : Hittable {
+    HBox boundary; MatPtr phase_function; Float neg_inv_density;
+    ConstantMedium(HBox b, Float d, TexPtr texture) : boundary(std::move(b)), phase_function(new Isotropic(texture)), neg_inv_density(-1.0 / d) {} /* :22-28 */
+    bool bounding_box(Float t0, Float t1, AABB& out) const override { return boundary->bounding_box(t0, t1, out); }
+    bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override { /* :58-113 */
+        HitRecord rec1, rec2;
+        if (!boundary->hit(ray, -RT_INF, RT_INF, rng, rec1)) return false;
+        if (!boundary->hit(ray, rec1.t + 0.0001, RT_INF, rng, rec2)) return false;
+        rec1.t = rt_max(rec1.t, t_min);
+        rec2.t = rt_min(rec2.t, t_max);
+        if (rec1.t >= rec2.t) return false;
+        rec1.t = rt_max(rec1.t, 0.0);
+        Float ray_length = rt_mag(ray.direction);
+        Float distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
+        Float hit_distance = neg_inv_density * rt_log(rt_gen_f64(rng));
+        if (hit_distance > distance_inside_boundary) return false;
+        Float t = rec1.t + hit_distance / ray_length;
+        out.t = t; out.position = ray.at(t); out.normal = rt_v3(1.0, 0.0, 0.0);
+        out.u = 0.0; out.v = 0.0; out.front_face = true; out.material = phase_function.get();
+        return true;
+    }
+};
+
+/* ---- camera.rs ---- */
+struct Camera {
+    V3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+    Float lens_radius, time0, time1;
+    Camera() {}
+    Camera(V3 look_from, V3 look_at, V3 vup, Float vfov_deg, Float aspect_ratio, Float aperture, Float focus_dist, Float t0, Float t1) { /* :22-59 */
+        Float theta = vfov_deg * (RT_PI / 180.0);
+        Float h = rt_tan(theta / 2.0);
+        Float viewport_height = 2.0 * h;
+        Float viewport_width = aspect_ratio * viewport_height;
+        w = rt_normalize(look_from - look_at);
+        u = rt_normalize(rt_cross(vup, w));
+        v = rt_cross(w, u);
+        origin = look_from;
+        horizontal = focus_dist * viewport_width * u;
+        vertical = focus_dist * viewport_height * v;
+        lower_left_corner = origin - horizontal / 2.0 - vertical / 2.0 - focus_dist * w;
+        lens_radius = aperture / 2.0;
+        time0 = t0; time1 = t1;
+    }
+    Ray get_ray(Float s, Float t, MyRng& rng) const { /* :61-73 */
+        V3 rd = lens_radius * random_in_unit_disk(rng);
+        V3 offset = u * rd.x + v * rd.y;
+        Ray r;
+        r.origin = origin + offset;
+        r.direction = lower_left_corner + s * horizontal + t * vertical - origin - offset;
+        r.time = rt_gen_range(rng, time0, time1);
+        return r;
+    }
+};
+
+/* ---- main.rs:51-116 ---- */
+static V3 ray_color(const Ray& ray, V3 background, const Hittable& world, const Hittable& lights, size_t depth, MyRng& rng) {
+    if (depth == 0) return rt_v3(0.0, 0.0, 0.0);
+    g_segments++;
+    HitRecord hit_record;
+    if (world.hit(ray, 0.001, RT_INF, rng, hit_record)) {
+        V3 emitted = hit_record.material->emitted(ray, hit_record, hit_record.u, hit_record.v, hit_record.position);
+        Scatter sc;
+        if (hit_record.material->scatter(ray, hit_record, rng, sc)) {
+            if (!sc.is_specular) {
+                HittablePdf p0(&lights, hit_record.position);
+                MixturePdf mixed_pdf(&p0, sc.pdf.get());
+                Ray scatterd;
+                scatterd.origin = hit_record.position;
+                scatterd.direction = mixed_pdf.generate(rng);
+                scatterd.time = hit_record.t;
+                Float pdf = mixed_pdf.value(scatterd.direction, rng);
+                Float spdf = hit_record.material->scattering_pdf(ray, hit_record, scatterd, rng);
+                V3 next = ray_color(scatterd, background, world, lights, depth - 1, rng);
+                return emitted + rt_mul(sc.attenuation * spdf, next / pdf);
+            }
+            return rt_mul(sc.attenuation, ray_color(sc.specular, background, world, lights, depth - 1, rng));
+        }
+        return emitted;
+    }
+    return background;
+}
+/* ---- main.rs:118-190 ---- */
+static V3 ray_color_without_light_objects(const Ray& ray, V3 background, const Hittable& world, size_t depth, MyRng& rng) {
+    if (depth == 0) return rt_v3(0.0, 0.0, 0.0);
+    g_segments++;
+    HitRecord hit_record;
+    if (world.hit(ray, 0.001, RT_INF, rng, hit_record)) {
+        V3 emitted = hit_record.material->emitted(ray, hit_record, hit_record.u, hit_record.v, hit_record.position);
+        Scatter sc;
+        if (hit_record.material->scatter(ray, hit_record, rng, sc)) {
+            if (!sc.is_specular) {
+                Ray scatterd;
+                scatterd.origin = hit_record.position;
+                scatterd.direction = sc.pdf->generate(rng);
+                scatterd.time = hit_record.t;
+                Float pdf_value = sc.pdf->value(scatterd.direction, rng);
+                Float spdf = hit_record.material->scattering_pdf(ray, hit_record, scatterd, rng);
+                V3 next = ray_color_without_light_objects(scatterd, background, world, depth - 1, rng);
+                return emitted + rt_mul(sc.attenuation * spdf, next / pdf_value);
+            }
+            return rt_mul(sc.attenuation, ray_color_without_light_objects(sc.specular, background, world, depth - 1, rng));
+        }
+        return emitted;
+    }
+    return background;
+}
+
+/* ---- scenes, main.rs:192-795 ---- */
+static TexPtr solid(Float r, Float g, Float b) { return TexPtr(new SolidColor(rt_v3(r, g, b))); }
+static MatPtr lambert(TexPtr t) { return MatPtr(new Lambertian(t)); }
+
+struct SceneArgs { const uint8_t* earth; uint32_t ew, eh; };
+
+static std::unique_ptr<BVHNode> random_scene(MyRng& rng) { /* main.rs:192-295 */
+    MatPtr ground_material = lambert(TexPtr(new CheckerTexture(/*odd*/ solid(0.9, 0.9, 0.9), /*even*/ solid(0.2, 0.3, 0.1))));
+    std::vector<HBox> world;
+    world.emplace_back(new Sphere(rt_v3(0.0, -1000.0, 0.0), 1000.0, ground_material));
+    for (int a = -11; a < 11; ++a)
+        for (int b = -11; b < 11; ++b) {
+            Float choose_mat = rt_gen_f64(rng);
+            Float cx = (Float)a + 0.9 * rt_gen_f64(rng);
+            Float cz = (Float)b + 0.9 * rt_gen_f64(rng);
+            V3 center = rt_v3(cx, 0.2, cz);
+            if (rt_mag(center - rt_v3(4.0, 0.2, 0.0)) > 0.9) {
+                if (choose_mat < 0.8) {
+                    Float r0 = rt_gen_f64(rng), g0 = rt_gen_f64(rng), b0 = rt_gen_f64(rng);
+                    Float r1 = rt_gen_f64(rng), g1 = rt_gen_f64(rng), b1 = rt_gen_f64(rng);
+                    V3 albedo = rt_mul(rt_v3(r0, g0, b0), rt_v3(r1, g1, b1));
+                    V3 center2 = center + rt_v3(0.0, rt_gen_range(rng, 0.0, 0.5), 0.0);
+                    world.emplace_back(new MovingSphere(center, center2, 0.0, 1.0, 0.2, lambert(TexPtr(new SolidColor(albedo)))));
+                } else if (choose_mat < 0.95) {
+                    Float r = rt_gen_range(rng, 0.5, 1.0), g = rt_gen_range(rng, 0.5, 1.0), bl = rt_gen_range(rng, 0.5, 1.0);
+                    Float fuzz = rt_gen_range(rng, 0.5, 1.0);
+                    world.emplace_back(new Sphere(center, 0.2, MatPtr(new Metal(rt_v3(r, g, bl), fuzz))));
+                } else {
+                    world.emplace_back(new Sphere(center, 0.2, MatPtr(new Dielectric(1.5))));
+                }
+            }
+        }
+    world.emplace_back(new Sphere(rt_v3(0.0, 1.0, 0.0), 1.0, MatPtr(new Dielectric(1.5))));
+    world.emplace_back(new Sphere(rt_v3(-4.0, 1.0, 0.0), 1.0, lambert(solid(0.4, 0.2, 0.1))));
+    world.emplace_back(new Sphere(rt_v3(4.0, 1.0, 0.0), 1.0, MatPtr(new Metal(rt_v3(0.7, 0.6, 0.5), 0.0))));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> two_spheres(MyRng& rng) { /* main.rs:297-323 */
+    MatPtr m = lambert(TexPtr(new CheckerTexture(solid(0.9, 0.9, 0.9), solid(0.2, 0.3, 0.1))));
+    std::vector<HBox> world;
+    world.emplace_back(new Sphere(rt_v3(0.0, -10.0, 0.0), 10.0, m));
+    world.emplace_back(new Sphere(rt_v3(0.0, 10.0, 0.0), 10.0, m));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> two_perlin_spheres(MyRng& rng) { /* main.rs:325-344 */
+    MatPtr pertext = lambert(TexPtr(new NoiseTexture(4.0, rng)));
+    std::vector<HBox> world;
+    world.emplace_back(new Sphere(rt_v3(0.0, -1000.0, 0.0), 1000.0, pertext));
+    world.emplace_back(new Sphere(rt_v3(0.0, 2.0, 0.0), 2.0, pertext));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> earth(MyRng& rng, const SceneArgs& a) { /* main.rs:346-358 */
+    MatPtr earth_surface = lambert(TexPtr(new ImageTexture(a.earth, a.ew, a.eh)));
+    std::vector<HBox> world;
+    world.emplace_back(new Sphere(rt_v3(0.0, 0.0, 0.0), 2.0, earth_surface));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> simple_light(MyRng& rng) { /* main.rs:360-393 */
+    MatPtr pertext = lambert(TexPtr(new NoiseTexture(4.0, rng)));
+    MatPtr difflight(new DiffuseLight(solid(4.0, 4.0, 4.0)));
+    std::vector<HBox> world;
+    world.emplace_back(new Sphere(rt_v3(0.0, -1000.0, 0.0), 1000.0, pertext));
+    world.emplace_back(new Sphere(rt_v3(0.0, 2.0, 0.0), 2.0, pertext));
+    world.emplace_back(new XYRect(3.0, 5.0, 1.0, 3.0, -2.0, difflight));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> cornel_box(MyRng& rng) { /* main.rs:395-512 */
+    MatPtr red = lambert(solid(0.65, 0.05, 0.05));
+    MatPtr white = lambert(solid(0.73, 0.73, 0.73));
+    MatPtr green = lambert(solid(0.12, 0.45, 0.15));
+    MatPtr light(new DiffuseLight(solid(15.0, 15.0, 15.0)));
+    MatPtr aluminum(new Metal(rt_v3(0.8, 0.85, 0.88), 0.0));
+    HBox box1(new AABox(rt_v3(0.0, 0.0, 0.0), rt_v3(165.0, 330.0, 165.0), aluminum, rng));
+    box1.reset(new RotateY(std::move(box1), 0.0, 1.0, 15.0));
+    box1.reset(new Translate(std::move(box1), rt_v3(265.0, 0.0, 295.0)));
+    MatPtr grass(new Dielectric(1.5));
+    std::vector<HBox> world;
+    world.emplace_back(new YZRect(0.0, 555.0, 0.0, 555.0, 555.0, green));
+    world.emplace_back(new YZRect(0.0, 555.0, 0.0, 555.0, 0.0, red));
+    world.emplace_back(new FlipFace(HBox(new XZRect(213.0, 343.0, 227.0, 332.0, 554.0, light))));
+    world.emplace_back(new XZRect(0.0, 555.0, 0.0, 555.0, 0.0, white));
+    world.emplace_back(new XZRect(0.0, 555.0, 0.0, 555.0, 555.0, white));
+    world.emplace_back(new XYRect(0.0, 555.0, 0.0, 555.0, 555.0, white));
+    world.push_back(std::move(box1));
+    world.emplace_back(new Sphere(rt_v3(190.0, 90.0, 190.0), 90.0, grass));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> cornel_smoke(MyRng& rng) { /* main.rs:514-633 */
+    MatPtr red = lambert(solid(0.65, 0.05, 0.05));
+    MatPtr white = lambert(solid(0.73, 0.73, 0.73));
+    MatPtr green = lambert(solid(0.12, 0.45, 0.15));
+    MatPtr light(new DiffuseLight(solid(7.0, 7.0, 7.0)));
+    HBox box1(new AABox(rt_v3(0.0, 0.0, 0.0), rt_v3(165.0, 330.0, 165.0), white, rng));
+    box1.reset(new RotateY(std::move(box1), 0.0, 1.0, 15.0));
+    box1.reset(new Translate(std::move(box1), rt_v3(265.0, 0.0, 295.0)));
+    HBox box2(new AABox(rt_v3(0.0, 0.0, 0.0), rt_v3(165.0, 165.0, 165.0), white, rng));
+    box2.reset(new RotateY(std::move(box2), 0.0, 1.0, -18.0));
+    box2.reset(new Translate(std::move(box2), rt_v3(130.0, 0.0, 65.0)));
+    HBox smoke1(new ConstantMedium(std::move(box1), 0.01, solid(0.0, 0.0, 0.0)));
+    HBox smoke2(new ConstantMedium(std::move(box2), 0.01, solid(1.0, 1.0, 1.0)));
+    std::vector<HBox> world;
+    world.emplace_back(new YZRect(0.0, 555.0, 0.0, 555.0, 555.0, green));
+    world.emplace_back(new YZRect(0.0, 555.0, 0.0, 555.0, 0.0, red));
+    world.emplace_back(new FlipFace(HBox(new XZRect(113.0, 443.0, 127.0, 432.0, 554.0, light))));
+    world.emplace_back(new XZRect(0.0, 555.0, 0.0, 555.0, 0.0, white));
+    world.emplace_back(new XZRect(0.0, 555.0, 0.0, 555.0, 555.0, white));
+    world.emplace_back(new XYRect(0.0, 555.0, 0.0, 555.0, 555.0, white));
+    world.push_back(std::move(smoke1));
+    world.push_back(std::move(smoke2));
+    return BVHNode::make(std::move(world), 0.0, 1.0, rng);
+}
+static std::unique_ptr<BVHNode> final_scene(MyRng& rng, const SceneArgs& a) { /* main.rs:635-795 */
+    MatPtr ground = lambert(solid(0.48, 0.83, 0.53));
+    const int BOXES_PER_SIDE = 20;
+    std::vector<HBox> boxes1;
+    for (int i = 0; i < BOXES_PER_SIDE; ++i)
+        for (int j = 0; j < BOXES_PER_SIDE; ++j) {
+            Float w = 100.0;
+            Float x0 = -1000.0 + (Float)i * w;
+            Float z0 = -1000.0 + (Float)j * w;
+            Float y0 = 0.0;
+            Float x1 = x0 + w;
+            Float y1 = rt_gen_range(rng, 1.0, 101.0);
+            Float z1 = z0 + w;
+            boxes1.emplace_back(new AABox(rt_v3(x0, y0, z0), rt_v3(x1, y1, z1), ground, rng));
+        }
+    std::vector<HBox> objects;
+    objects.push_back(BVHNode::make(std::move(boxes1), 0.0, 1.0, rng));
+    MatPtr light(new DiffuseLight(solid(7.0, 7.0, 7.0)));
+    objects.emplace_back(new FlipFace(HBox(new XZRect(123.0, 423.0, 147.0, 412.0, 554.0, light))));
+    V3 center1 = rt_v3(400.0, 400.0, 200.0);
+    V3 center2 = center1 + rt_v3(30.0, 0.0, 0.0);
+    objects.emplace_back(new MovingSphere(center1, center2, 0.0, 1.0, 50.0, lambert(solid(0.7, 0.3, 0.1))));
+    objects.emplace_back(new Sphere(rt_v3(260.0, 150.0, 45.0), 50.0, MatPtr(new Dielectric(1.5))));
+    objects.emplace_back(new Sphere(rt_v3(0.0, 150.0, 145.0), 50.0, MatPtr(new Metal(rt_v3(0.8, 0.8, 0.9), 1.0))));
+    HBox boundary(new Sphere(rt_v3(360.0, 150.0, 145.0), 70.0, MatPtr(new Dielectric(1.5))));
+    objects.emplace_back(new Sphere(rt_v3(360.0, 150.0, 145.0), 70.0, MatPtr(new Dielectric(1.5))));
+    objects.emplace_back(new ConstantMedium(std::move(boundary), 0.2, solid(0.2, 0.4, 0.9)));
+    boundary.reset(new Sphere(rt_v3(0.0, 0.0, 0.0), 5000.0, MatPtr(new Dielectric(1.5))));
+    objects.emplace_back(new ConstantMedium(std::move(boundary), 0.0001, solid(1.0, 1.0, 1.0)));
+    MatPtr emat = lambert(TexPtr(new ImageTexture(a.earth, a.ew, a.eh)));
+    objects.emplace_back(new Sphere(rt_v3(400.0, 200.0, 400.0), 100.0, emat));
+    MatPtr pertext = lambert(TexPtr(new NoiseTexture(0.1, rng)));
+    objects.emplace_back(new Sphere(rt_v3(220.0, 280.0, 300.0), 80.0, pertext));
+    std::vector<HBox> boxes2;
+    MatPtr white = lambert(solid(0.73, 0.73, 0.73));
+    const int ns = 1000;
+    for (int i = 0; i < ns; ++i) {
+        Float x = rt_gen_range(rng, 0.0, 165.0), y = rt_gen_range(rng, 0.0, 165.0), z = rt_gen_range(rng, 0.0, 165.0);
+        boxes2.emplace_back(new Sphere(rt_v3(x, y, z), 10.0, white));
+    }
+    HBox b2(new RotateY(BVHNode::make(std::move(boxes2), 0.0, 1.0, rng), 0.0, 1.0, 15.0));
+    objects.emplace_back(new Translate(std::move(b2), rt_v3(-100.0, 270.0, 395.0)));
+    return BVHNode::make(std::move(objects), 0.0, 1.0, rng);
+}
+
+/* what main.rs:807-951 assembles */
+struct Scene {
+    std::unique_ptr<BVHNode> world;
+    std::unique_ptr<HittableList> lights; /* None -> null */
+    V3 background;
+    Camera camera;
+    uint32_t image_width, samples_per_pixel;
+};
+
+static Scene build_scene(int arm, uint64_t build_seed, Float aspect_ratio, const SceneArgs& a) {
+    Scene s;
+    MyRng rng = rt_rng_build(build_seed);
+    MatPtr null_mat(new NullMaterial());
+    s.image_width = 400; s.samples_per_pixel = 100;
+    s.background = rt_v3(0.70, 0.80, 1.00);
+    V3 look_from = rt_v3(13.0, 2.0, 3.0), look_at = rt_v3(0.0, 0.0, 0.0);
+    Float vfov = 20.0, aperture = 0.0;
+    switch (arm) {
+        case 0: s.samples_per_pixel = 500; s.world = random_scene(rng); aperture = 0.1; break;
+        case 1: s.world = two_spheres(rng); break;
+        case 2: s.world = two_perlin_spheres(rng); break;
+        case 3: s.world = earth(rng, a); break;
+        case 4:
+            s.samples_per_pixel = 400; s.world = simple_light(rng);
+            s.background = rt_v3(0.0, 0.0, 0.0); look_from = rt_v3(26.0, 3.0, 6.0); look_at = rt_v3(0.0, 2.0, 0.0);
+            break;
+        case 5:
+            s.image_width = 600; s.samples_per_pixel = 100; s.world = cornel_box(rng);
+            s.lights.reset(new HittableList());
+            s.lights->items.emplace_back(new XZRect(213.0, 343.0, 227.0, 332.0, 554.0, null_mat));
+            s.lights->items.emplace_back(new Sphere(rt_v3(190.0, 90.0, 190.0), 90.0, null_mat));
+            s.background = rt_v3(0.0, 0.0, 0.0); look_from = rt_v3(278.0, 278.0, -800.0); look_at = rt_v3(278.0, 278.0, 0.0); vfov = 40.0;
+            break;
+        case 6:
+            s.image_width = 600; s.samples_per_pixel = 200; s.world = cornel_smoke(rng);
+            s.lights.reset(new HittableList());
+            s.lights->items.emplace_back(new XZRect(113.0, 443.0, 127.0, 432.0, 554.0, null_mat));
+            s.background = rt_v3(0.0, 0.0, 0.0); look_from = rt_v3(278.0, 278.0, -800.0); look_at = rt_v3(278.0, 278.0, 0.0); vfov = 40.0;
+            break;
+        default:
+            s.image_width = 800; s.samples_per_pixel = 10000; s.world = final_scene(rng, a);
+            s.lights.reset(new HittableList());
+            s.lights->items.emplace_back(new XZRect(123.0, 423.0, 147.0, 412.0, 554.0, null_mat));
+            s.background = rt_v3(0.0, 0.0, 0.0); look_from = rt_v3(478.0, 278.0, -600.0); look_at = rt_v3(278.0, 278.0, 0.0); vfov = 40.0;
+            break;
+    }
+    s.camera = Camera(look_from, look_at, rt_v3(0.0, 1.0, 0.0), vfov, aspect_ratio, aperture, 10.0, 0.0, 1.0);
+    return s;
+}
+
+/* color.rs:14-21 */
+static V3 into_sampled(V3 c, uint32_t sample_per_pixel) {
+    Float scale = 1.0 / (Float)sample_per_pixel;
+    Float r = rt_isnan(c.x) ? 0.0 : c.x;
+    Float g = rt_isnan(c.y) ? 0.0 : c.y;
+    Float b = rt_isnan(c.z) ? 0.0 : c.z;
+    return rt_v3(r, g, b) * scale;
+}
+/* color.rs:56-65 */
+static uint32_t quantize(Float c) {
+    Float s = rt_sqrt(c);
+    if (s < 0.0) s = 0.0;      /* f64::clamp keeps NaN */
+    if (s > 0.999) s = 0.999;
+    Float q = 256.0 * s;
+    return (q != q) ? 0u : (uint32_t)q; /* `as usize`: NaN -> 0 */
+}
+
+} // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_scene { Scene s; };
+
+/* returns NULL on the reference's panics */
+orc_scene* orc_scene_build(int arm, uint64_t build_seed, double aspect_ratio, const uint8_t* earth, uint32_t ew, uint32_t eh, uint32_t defaults[3]) {
+    try {
+        SceneArgs a{earth, ew, eh};
+        bool needs_earth = (arm == 3) || (arm < 0 || arm > 6);
+        if (needs_earth && !earth) return nullptr;
+        orc_scene* o = new orc_scene();
+        o->s = build_scene(arm, build_seed, aspect_ratio, a);
+        if (defaults) {
+            defaults[0] = o->s.image_width;
+            defaults[1] = (uint32_t)((double)o->s.image_width / aspect_ratio);
+            defaults[2] = o->s.samples_per_pixel;
+        }
+        return o;
+    } catch (...) { return nullptr; }
+}
+void orc_scene_free(orc_scene* o) { delete o; }
+
+/* The sample loop, main.rs:957-1001, for the tile [x0,x0+tw) x [y0,y0+th) (y = row index j).
+ * out[(y-y0)*tw + (x-x0)][3]: into_sampled means, or raw sums if out_sum != 0.
+ * Samples sample_offset .. sample_offset+spp-1 are summed in order. */
+int orc_render(const orc_scene* o, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t tw, uint32_t th,
+               uint32_t spp, uint32_t sample_offset, uint32_t max_depth, uint32_t global_seed, int out_sum, int threads,
+               double* out, uint64_t* segments_out) {
+    if (!o || !out || width < 2 || height < 2 || spp == 0) return -1;
+    const Scene& s = o->s;
+    if (threads < 1) threads = 1;
+    std::atomic<uint32_t> next_row(0);
+    std::atomic<uint64_t> seg_total(0);
+    auto worker = [&]() {
+        g_segments = 0;
+        for (;;) {
+            uint32_t r = next_row.fetch_add(1);
+            if (r >= th) break;
+            uint32_t j = y0 + r;
+            for (uint32_t c = 0; c < tw; ++c) {
+                uint32_t i = x0 + c;
+                V3 pixel_color = rt_v3(0.0, 0.0, 0.0);
+                for (uint32_t k = 0; k < spp; ++k) {
+                    MyRng rng = rt_rng_pixel_sample((uint64_t)j * width + i, sample_offset + k, global_seed); /* main.rs:964 */
+                    Float u = ((Float)i + rt_gen_f64(rng)) / (Float)(width - 1);
+                    Float v = ((Float)j + rt_gen_f64(rng)) / (Float)(height - 1);
+                    Ray ray = s.camera.get_ray(u, v, rng);
+                    V3 col = s.lights ? ray_color(ray, s.background, *s.world, *s.lights, max_depth, rng)
+                                      : ray_color_without_light_objects(ray, s.background, *s.world, max_depth, rng);
+                    pixel_color = pixel_color + col;
+                }
+                V3 res = out_sum ? pixel_color : into_sampled(pixel_color, spp);
+                double* dst = out + ((size_t)r * tw + c) * 3;
+                dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+            }
+        }
+        seg_total += g_segments;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (segments_out) *segments_out = seg_total.load();
+    return 0;
+}
+
+void orc_resolve(const double* sums, uint64_t n, uint32_t spp, double* means) {
+    for (uint64_t i = 0; i < n; ++i) { V3 m = into_sampled(rt_v3(sums[i * 3], sums[i * 3 + 1], sums[i * 3 + 2]), spp); means[i * 3] = m.x; means[i * 3 + 1] = m.y; means[i * 3 + 2] = m.z; }
+}
+void orc_quantize(const double* means, uint64_t n, uint8_t* out) { for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)quantize(means[i]); }
+
+/* ---- leaf entry points for known-answer tests ---- */
+/* hit of one primitive: kind 0 sphere(c[3],r) 1 xy 2 xz 3 yz (a0,a1,b0,b1,k) 4 moving sphere (c0[3],c1[3],t0,t1,r).
+ * out = {hit?, t, px,py,pz, nx,ny,nz, u, v, front_face} */
+int orc_prim_hit(int kind, const double* prm, const double o[3], const double d[3], double time, double t_min, double t_max, double out[11]) {
+    MatPtr m(new NullMaterial());
+    std::unique_ptr<Hittable> h;
+    switch (kind) {
+        case 0: h.reset(new Sphere(rt_v3(prm[0], prm[1], prm[2]), prm[3], m)); break;
+        case 1: h.reset(new XYRect(prm[0], prm[1], prm[2], prm[3], prm[4], m)); break;
+        case 2: h.reset(new XZRect(prm[0], prm[1], prm[2], prm[3], prm[4], m)); break;
+        case 3: h.reset(new YZRect(prm[0], prm[1], prm[2], prm[3], prm[4], m)); break;
+        case 4: h.reset(new MovingSphere(rt_v3(prm[0], prm[1], prm[2]), rt_v3(prm[3], prm[4], prm[5]), prm[6], prm[7], prm[8], m)); break;
+        default: return -1;
+    }
+    Ray r{rt_v3(o[0], o[1], o[2]), rt_v3(d[0], d[1], d[2]), time};
+    MyRng rng = rt_rng_build(0);
+    HitRecord rec;
+    bool ok = h->hit(r, t_min, t_max, rng, rec);
+    out[0] = ok ? 1.0 : 0.0;
+    if (ok) {
+        out[1] = rec.t; out[2] = rec.position.x; out[3] = rec.position.y; out[4] = rec.position.z;
+        out[5] = rec.normal.x; out[6] = rec.normal.y; out[7] = rec.normal.z; out[8] = rec.u; out[9] = rec.v;
+        out[10] = rec.front_face ? 1.0 : 0.0;
+    }
+    return 0;
+}
+int orc_aabb_hit(const double mn[3], const double mx[3], const double o[3], const double d[3], double t_min, double t_max) {
+    AABB b{rt_v3(mn[0], mn[1], mn[2]), rt_v3(mx[0], mx[1], mx[2])};
+    Ray r{rt_v3(o[0], o[1], o[2]), rt_v3(d[0], d[1], d[2]), 0.0};
+    return b.hit(r, t_min, t_max) ? 1 : 0;
+}
+double orc_reflectance(double cosine, double ref_idx) { return reflectance(cosine, ref_idx); }
+void orc_reflect(const double v[3], const double n[3], double out[3]) { V3 r = reflect(rt_v3(v[0], v[1], v[2]), rt_v3(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_refract(const double uv[3], const double n[3], double eta, double out[3]) { V3 r = refract(rt_v3(uv[0], uv[1], uv[2]), rt_v3(n[0], n[1], n[2]), eta); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_sphere_uv(const double p[3], double out[2]) { sphere_uv(rt_v3(p[0], p[1], p[2]), out[0], out[1]); }
+void orc_onb(const double n[3], double out[9]) {
+    Onb o = Onb::from_w(rt_v3(n[0], n[1], n[2]));
+    out[0] = o.u.x; out[1] = o.u.y; out[2] = o.u.z; out[3] = o.v.x; out[4] = o.v.y; out[5] = o.v.z; out[6] = o.w.x; out[7] = o.w.y; out[8] = o.w.z;
+}
+/* pdf_value / random of the two light kinds: kind 0 sphere, 2 xz rect */
+double orc_light_pdf_value(int kind, const double* prm, const double o[3], const double v[3]) {
+    MatPtr m(new NullMaterial());
+    MyRng rng = rt_rng_build(0);
+    if (kind == 0) return Sphere(rt_v3(prm[0], prm[1], prm[2]), prm[3], m).pdf_value(rt_v3(o[0], o[1], o[2]), rt_v3(v[0], v[1], v[2]), rng);
+    return XZRect(prm[0], prm[1], prm[2], prm[3], prm[4], m).pdf_value(rt_v3(o[0], o[1], o[2]), rt_v3(v[0], v[1], v[2]), rng);
+}
+/* camera ray for (s,t) with the stream of (pixel_seed, sample): out = o[3], d[3], time */
+void orc_camera_ray(const orc_scene* sc, double s, double t, uint64_t pixel_seed, uint32_t sample, double out[7]) {
+    MyRng rng = rt_rng_pixel_sample(pixel_seed, sample, 0);
+    Ray r = sc->s.camera.get_ray(s, t, rng);
+    out[0] = r.origin.x; out[1] = r.origin.y; out[2] = r.origin.z; out[3] = r.direction.x; out[4] = r.direction.y; out[5] = r.direction.z; out[6] = r.time;
+}
+/* numerical contract on the host, same selectors as rt1w_debug_eval */
+void orc_num_eval(int fn, const double* a, const double* b, double* out, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        double x = a[i], y = b[i], r = 0.0;
+        switch (fn) {
+            case 0: r = x / y; break;
+            case 1: r = rt_sqrt(rt_abs(x)); break;
+            case 2: r = rt_sin(x); break;
+            case 3: r = rt_cos(x); break;
+            case 4: r = rt_acos(x / (rt_abs(x) + 1.0)); break;
+            case 5: r = rt_atan2(x, y); break;
+            case 6: r = rt_log(rt_abs(y)); break;
+            case 7: { RtRng g = rt_rng_pixel_sample(i, (uint32_t)rt_d2u(x), 0u); r = rt_gen_f64(g); } break;
+            case 8: { RtRng g = rt_rng_pixel_sample(i, (uint32_t)rt_d2u(x), 0u); (void)rt_gen_f64(g); r = rt_gen_range(g, -1.0, 1.0); } break;
+            case 9: r = rt_floor(x); break;
+            case 10: r = rt_tan(x); break;
+            default: break;
+        }
+        out[i] = r;
+    }
+}
+void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    RtPhiloxOut r = rt_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.w0; out[1] = r.w1; out[2] = r.w2; out[3] = r.w3;
+}
+/* first n draws of a build stream, by shape: 0 u32, 1 f64, 2 range(lo,hi), 3 below(m) */
+void orc_stream(uint64_t seed, int shape, double lo, double hi, uint32_t m, double* out, uint32_t n) {
+    RtRng r = rt_rng_build(seed);
+    for (uint32_t i = 0; i < n; ++i) {
+        switch (shape) {
+            case 0: out[i] = (double)rt_next_u32(r); break;
+            case 1: out[i] = rt_gen_f64(r); break;
+            case 2: out[i] = rt_gen_range(r, lo, hi); break;
+            default: out[i] = (double)rt_gen_below(r, m); break;
+        }
+    }
+}
+
+} /* extern "C" */

@@ -1,0 +1,345 @@
+"""raytracing-1w_amd -- Python host binding of librt1w.so (the MI355X path tracer).
+
+This is plumbing over the C ABI in ``include/rt1w.h``: every call goes to the
+shared library, whose render path is the HIP kernel.  There is no Python or CPU
+fallback -- if the library is missing the import fails, and without a GPU
+``Context`` raises.
+
+The package name has a hyphen (mandated layout), so import it with::
+
+    import importlib
+    rt = importlib.import_module("raytracing-1w_amd")
+
+Method names follow the reference's constructors (src/sphere.rs, src/aarect.rs,
+src/material.rs, src/texture.rs, src/bvh.rs, src/camera.rs of hatoo/raytracing-1w).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt1w.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "librt1w.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C raytracing-1w_amd/csrc` (needs hipcc, gfx950). There is no fallback path."
+    )
+
+_lib = C.CDLL(LIB_PATH)
+
+OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_STATE = -1, -2, -3, -4, -5
+OUT_SUM = 1
+
+
+class Rt1wError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt1w error {code}: {msg}")
+        self.code = code
+
+
+class RenderParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
+        "max_depth", "global_seed", "chunk", "flags")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("kernel_ms", C.c_double),
+                ("total_ms", C.c_double), ("chunk", C.c_uint32), ("n_chunks", C.c_uint32),
+                ("grid", C.c_uint32), ("block", C.c_uint32)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_lights", C.c_uint32), ("n_materials", C.c_uint32),
+                ("n_textures", C.c_uint32), ("n_perlin", C.c_uint32), ("stack_need", C.c_uint32),
+                ("scope_depth", C.c_uint32), ("has_media", C.c_uint32), ("bytes", C.c_uint64)]
+
+
+_P = C.c_void_p
+_D3 = C.c_double * 3
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig("rt1w_last_error", C.c_char_p)
+_sig("rt1w_version", C.c_char_p)
+_sig("rt1w_scene_create", C.c_int, C.c_uint64, C.POINTER(_P))
+_sig("rt1w_scene_destroy", None, _P)
+_sig("rt1w_scene_rng_f64", C.c_int, _P, C.POINTER(C.c_double))
+_sig("rt1w_scene_rng_range", C.c_int, _P, C.c_double, C.c_double, C.POINTER(C.c_double))
+_sig("rt1w_texture_solid", C.c_int, _P, _D3)
+_sig("rt1w_texture_checker", C.c_int, _P, C.c_int, C.c_int)
+_sig("rt1w_texture_noise", C.c_int, _P, C.c_double)
+_sig("rt1w_texture_noise_tables", C.c_int, _P, C.c_double, _P, _P, _P, _P)
+_sig("rt1w_texture_image", C.c_int, _P, _P, C.c_uint32, C.c_uint32)
+_sig("rt1w_material_lambertian", C.c_int, _P, C.c_int)
+_sig("rt1w_material_metal", C.c_int, _P, _D3, C.c_double)
+_sig("rt1w_material_dielectric", C.c_int, _P, C.c_double)
+_sig("rt1w_material_diffuse_light", C.c_int, _P, C.c_int)
+_sig("rt1w_material_null", C.c_int, _P)
+_sig("rt1w_hittable_sphere", C.c_int, _P, _D3, C.c_double, C.c_int)
+_sig("rt1w_hittable_moving_sphere", C.c_int, _P, _D3, _D3, C.c_double, C.c_double, C.c_double, C.c_int)
+for _n in ("xy", "xz", "yz"):
+    _sig(f"rt1w_hittable_{_n}_rect", C.c_int, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int)
+_sig("rt1w_hittable_aabox", C.c_int, _P, _D3, _D3, C.c_int)
+_sig("rt1w_hittable_translate", C.c_int, _P, C.c_int, _D3)
+_sig("rt1w_hittable_rotate_y", C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_double)
+_sig("rt1w_hittable_flip_face", C.c_int, _P, C.c_int)
+_sig("rt1w_hittable_constant_medium", C.c_int, _P, C.c_int, C.c_double, C.c_int)
+_sig("rt1w_hittable_bvh", C.c_int, _P, C.POINTER(C.c_int), C.c_uint32, C.c_double, C.c_double)
+_sig("rt1w_scene_set_world", C.c_int, _P, C.c_int)
+_sig("rt1w_scene_set_lights", C.c_int, _P, C.POINTER(C.c_int), C.c_uint32)
+_sig("rt1w_scene_set_background", C.c_int, _P, _D3)
+_sig("rt1w_scene_set_camera", C.c_int, _P, _D3, _D3, _D3, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
+_sig("rt1w_scene_commit", C.c_int, _P)
+_sig("rt1w_scene_build_reference", C.c_int, C.c_int, C.c_uint64, C.c_double, _P, C.c_uint32, C.c_uint32,
+     C.POINTER(_P), C.POINTER(C.c_uint32 * 3))
+_sig("rt1w_scene_get_info", C.c_int, _P, C.POINTER(SceneInfo))
+_sig("rt1w_scene_copy_flat", C.c_int64, _P, C.c_int, _P, C.c_uint64)
+_sig("rt1w_device_count", C.c_int)
+_sig("rt1w_context_create", C.c_int, C.c_int, _P, C.POINTER(_P))
+_sig("rt1w_context_destroy", None, _P)
+_sig("rt1w_default_chunk", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("rt1w_render", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
+_sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
+_sig("rt1w_resolve", C.c_int, _P, C.c_uint64, C.c_uint32, _P)
+_sig("rt1w_quantize", C.c_int, _P, C.c_uint64, _P)
+_sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
+_sig("rt1w_debug_eval", C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64)
+
+
+def last_error():
+    return _lib.rt1w_last_error().decode()
+
+
+def version():
+    return _lib.rt1w_version().decode()
+
+
+def _ck(rc):
+    if rc < 0:
+        raise Rt1wError(rc, last_error())
+    return rc
+
+
+def _v3(v):
+    return _D3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def device_count():
+    return _lib.rt1w_device_count()
+
+
+def default_chunk(tile_w, tile_h, spp):
+    return _lib.rt1w_default_chunk(tile_w, tile_h, spp)
+
+
+_EARTH = None
+
+
+def earth_rgb8():
+    """Decoded 1024x512 RGB8 earth map used by scene arms 3 and 7 (host one-shot).
+
+    The reference decodes assets/earthmap.jpg with the `image` crate (src/main.rs:347-348);
+    here PIL decodes the same asset; decoders may differ by 1 LSB per texel (unpinned).
+    """
+    global _EARTH
+    if _EARTH is None:
+        from PIL import Image
+        im = Image.open(os.path.join(_HERE, "assets", "earthmap.jpg")).convert("RGB")
+        _EARTH = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+    return _EARTH
+
+
+class Scene:
+    """Scene under construction / committed (rt1w_scene)."""
+
+    def __init__(self, build_seed=1, _handle=None, _defaults=None):
+        if _handle is None:
+            h = _P()
+            _ck(_lib.rt1w_scene_create(C.c_uint64(build_seed), C.byref(h)))
+            _handle = h
+        self._h = _handle
+        self.defaults = _defaults  # (image_width, image_height, samples_per_pixel) of a reference arm
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.rt1w_scene_destroy(self._h)
+            self._h = None
+
+    @classmethod
+    def reference(cls, arm, build_seed=1, aspect_ratio=None):
+        """The scene table of the reference's main (src/main.rs:815-937)."""
+        if aspect_ratio is None:
+            aspect_ratio = 1.0 if (arm in (5, 6) or arm < 0 or arm > 6) else 16.0 / 9.0
+        earth = None
+        ew = eh = 0
+        if arm == 3 or arm < 0 or arm > 6:
+            earth = earth_rgb8()
+            eh, ew = earth.shape[:2]
+        h = _P()
+        d = (C.c_uint32 * 3)()
+        _ck(_lib.rt1w_scene_build_reference(arm, C.c_uint64(build_seed), aspect_ratio,
+                                            earth.ctypes.data_as(_P) if earth is not None else None,
+                                            ew, eh, C.byref(h), C.byref(d)))
+        return cls(_handle=h, _defaults=(d[0], d[1], d[2]))
+
+    # draws from the build stream
+    def rng_f64(self):
+        x = C.c_double()
+        _ck(_lib.rt1w_scene_rng_f64(self._h, C.byref(x)))
+        return x.value
+
+    def rng_range(self, lo, hi):
+        x = C.c_double()
+        _ck(_lib.rt1w_scene_rng_range(self._h, lo, hi, C.byref(x)))
+        return x.value
+
+    # textures
+    def solid_color(self, rgb): return _ck(_lib.rt1w_texture_solid(self._h, _v3(rgb)))
+    def checker_texture(self, odd, even): return _ck(_lib.rt1w_texture_checker(self._h, odd, even))
+    def noise_texture(self, scale): return _ck(_lib.rt1w_texture_noise(self._h, scale))
+
+    def noise_texture_tables(self, scale, ranvec, perm_x, perm_y, perm_z):
+        rv = np.ascontiguousarray(ranvec, dtype=np.float64).reshape(768)
+        ps = [np.ascontiguousarray(p, dtype=np.uint32).reshape(256) for p in (perm_x, perm_y, perm_z)]
+        return _ck(_lib.rt1w_texture_noise_tables(self._h, scale, rv.ctypes.data_as(_P), *[p.ctypes.data_as(_P) for p in ps]))
+
+    def image_texture(self, rgb8):
+        a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w = a.shape[:2]
+        return _ck(_lib.rt1w_texture_image(self._h, a.ctypes.data_as(_P), w, h))
+
+    # materials
+    def lambertian(self, tex): return _ck(_lib.rt1w_material_lambertian(self._h, tex))
+    def metal(self, albedo, fuzz): return _ck(_lib.rt1w_material_metal(self._h, _v3(albedo), fuzz))
+    def dielectric(self, ir): return _ck(_lib.rt1w_material_dielectric(self._h, ir))
+    def diffuse_light(self, tex): return _ck(_lib.rt1w_material_diffuse_light(self._h, tex))
+    def null_material(self): return _ck(_lib.rt1w_material_null(self._h))
+
+    # hittables
+    def sphere(self, center, radius, mat): return _ck(_lib.rt1w_hittable_sphere(self._h, _v3(center), radius, mat))
+
+    def moving_sphere(self, c0, c1, t0, t1, radius, mat):
+        return _ck(_lib.rt1w_hittable_moving_sphere(self._h, _v3(c0), _v3(c1), t0, t1, radius, mat))
+
+    def xy_rect(self, x0, x1, y0, y1, k, mat): return _ck(_lib.rt1w_hittable_xy_rect(self._h, x0, x1, y0, y1, k, mat))
+    def xz_rect(self, x0, x1, z0, z1, k, mat): return _ck(_lib.rt1w_hittable_xz_rect(self._h, x0, x1, z0, z1, k, mat))
+    def yz_rect(self, y0, y1, z0, z1, k, mat): return _ck(_lib.rt1w_hittable_yz_rect(self._h, y0, y1, z0, z1, k, mat))
+    def aabox(self, p0, p1, mat): return _ck(_lib.rt1w_hittable_aabox(self._h, _v3(p0), _v3(p1), mat))
+    def translate(self, child, offset): return _ck(_lib.rt1w_hittable_translate(self._h, child, _v3(offset)))
+    def rotate_y(self, child, angle_deg, time0=0.0, time1=1.0): return _ck(_lib.rt1w_hittable_rotate_y(self._h, child, time0, time1, angle_deg))
+    def flip_face(self, child): return _ck(_lib.rt1w_hittable_flip_face(self._h, child))
+    def constant_medium(self, boundary, density, tex): return _ck(_lib.rt1w_hittable_constant_medium(self._h, boundary, density, tex))
+
+    def bvh_node(self, children, time0=0.0, time1=1.0):
+        arr = (C.c_int * len(children))(*children)
+        return _ck(_lib.rt1w_hittable_bvh(self._h, arr, len(children), time0, time1))
+
+    # scene level
+    def set_world(self, hid): _ck(_lib.rt1w_scene_set_world(self._h, hid))
+
+    def set_lights(self, ids):
+        arr = (C.c_int * max(1, len(ids)))(*ids)
+        _ck(_lib.rt1w_scene_set_lights(self._h, arr, len(ids)))
+
+    def set_background(self, rgb): _ck(_lib.rt1w_scene_set_background(self._h, _v3(rgb)))
+
+    def set_camera(self, look_from, look_at, vup, vfov_deg, aspect_ratio, aperture, focus_dist, time0, time1):
+        _ck(_lib.rt1w_scene_set_camera(self._h, _v3(look_from), _v3(look_at), _v3(vup), vfov_deg, aspect_ratio,
+                                       aperture, focus_dist, time0, time1))
+
+    def commit(self): _ck(_lib.rt1w_scene_commit(self._h))
+
+    def info(self):
+        i = SceneInfo()
+        _ck(_lib.rt1w_scene_get_info(self._h, C.byref(i)))
+        return {n: getattr(i, n) for n, _ in SceneInfo._fields_}
+
+    def flat(self, what):
+        """Bytes of one flat array (0 nodes,1 lights,2 materials,3 textures,4 perlin,5 images,6 camera+bg)."""
+        n = _lib.rt1w_scene_copy_flat(self._h, what, None, 0)
+        _ck(int(n))
+        buf = np.zeros(max(int(n), 1), dtype=np.uint8)
+        _ck(int(_lib.rt1w_scene_copy_flat(self._h, what, buf.ctypes.data_as(_P), int(n))))
+        return buf[:int(n)]
+
+
+class Context:
+    """One GPU + one HIP stream with the scene uploaded (rt1w_context)."""
+
+    def __init__(self, scene, device=0):
+        h = _P()
+        _ck(_lib.rt1w_context_create(device, scene._h, C.byref(h)))
+        self._h = h
+        self.scene = scene
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.rt1w_context_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum):
+        x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
+        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk,
+                            OUT_SUM if out_sum else 0)
+
+    def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False):
+        """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict)."""
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum)
+        out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
+        st = Stats()
+        _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
+        return out, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False):
+        """Same, into device memory `d_ptr` (int address, e.g. torch tensor .data_ptr())."""
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum)
+        st = Stats()
+        _ck(_lib.rt1w_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.byref(st)))
+        return {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def debug_eval(self, fn, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.empty_like(a)
+        _ck(_lib.rt1w_debug_eval(self._h, fn, a.ctypes.data_as(_P), b.ctypes.data_as(_P), out.ctypes.data_as(_P), a.size))
+        return out
+
+
+def resolve(sums, spp):
+    s = np.ascontiguousarray(sums, dtype=np.float64)
+    out = np.empty_like(s)
+    _ck(_lib.rt1w_resolve(s.ctypes.data_as(_P), s.size // 3, spp, out.ctypes.data_as(_P)))
+    return out
+
+
+def quantize(means):
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    out = np.empty(m.shape, dtype=np.uint8)
+    _ck(_lib.rt1w_quantize(m.ctypes.data_as(_P), m.size, out.ctypes.data_as(_P)))
+    return out
+
+
+def format_ppm(means):
+    """P3 text exactly as the reference prints it (src/main.rs:953,1003-1007); means[j, i, 3], row 0 = j = 0."""
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    h, w = m.shape[:2]
+    n = int(_lib.rt1w_format_ppm(m.ctypes.data_as(_P), w, h, None, 0))
+    _ck(n)
+    buf = C.create_string_buffer(n + 1)
+    _ck(int(_lib.rt1w_format_ppm(m.ctypes.data_as(_P), w, h, buf, n + 1)))
+    return buf.raw[:n].decode()

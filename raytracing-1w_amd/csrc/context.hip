@@ -1,0 +1,361 @@
+/* context.hip -- execution half of the C ABI: device context, the persistent-thread
+ * render kernel and the resolve kernel.  gfx950 only.
+ *
+ * Kernel shape (replaces the rayon loop of src/main.rs:957-1001):
+ *   - one lane owns one path at a time; a lane whose path ended regenerates in
+ *     place (next sample of its work item, or a new work item), so lanes of a
+ *     wave stay busy although path lengths differ (1..50 segments);
+ *   - a work item = (pixel, chunk of `chunk` consecutive samples).  Items are
+ *     handed out by one global counter; the first grid-size items are assigned
+ *     statically, later ones by a wave-aggregated atomic (one atomic per wave per
+ *     refill round: ballot + mbcnt prefix);
+ *   - the pixel sum of a chunk lives in registers and is stored once
+ *     (24 B per item, `partial[chunk][pixel]`); no floating-point atomics, so the
+ *     summation order -- and therefore every bit of the result -- is fixed:
+ *     sum over chunks in order of (sum over the chunk's samples in order);
+ *   - the BVH traversal stack is per-lane in LDS, laid out [entry][lane] so that a
+ *     wave's pushes/pops are bank-conflict free whatever depth each lane is at;
+ *   - Philox4x32-10 state is 11 VGPRs (rt1w_num.h), nothing RNG-related in memory.
+ */
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt1w.h"
+#include "rt_core.h"
+#include "scene.h"
+
+#define RT_BLOCK 256
+
+namespace {
+
+struct LdsStack {
+    uint32_t* base; /* this lane's entry 0; entry e at base[e * RT_BLOCK] */
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
+    __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
+};
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+/* counters[0] = next work item, counters[1] = traced segments */
+__global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+                                                            unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+
+    const unsigned long long n_items = rt_item_count(f);
+    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
+    unsigned long long item = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    bool fresh = true; /* `item` holds an id that was not decoded yet */
+    bool have = false;
+    uint32_t px = 0, py = 0, chunk = 0, s = 0, s_end = 0;
+    RtV3 sum = rt_v3(0.0, 0.0, 0.0);
+    RtPath path;
+    path.alive = false;
+    unsigned long long segs = 0;
+
+    for (;;) {
+        if (!path.alive) {
+            if (have && s == s_end) {
+                double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
+                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
+                have = false;
+            }
+            while (!have) {
+                if (!fresh) {
+                    /* wave-aggregated fetch: the lanes that need an item share one atomic */
+                    unsigned long long need = __ballot(1);
+                    uint32_t cnt = (uint32_t)__popcll(need);
+                    uint32_t rank = lane_prefix(need);
+                    unsigned long long base_item = 0;
+                    if (rank == 0u) base_item = atomicAdd(&counters[0], (unsigned long long)cnt);
+                    /* rank 0 is the first active lane: broadcast its value */
+                    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_item);
+                    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_item >> 32));
+                    item = (((unsigned long long)hi << 32) | lo) + rank;
+                }
+                fresh = false;
+                if (item >= n_items) break;
+                rt_item_decode(f, item, px, py, chunk);
+                if (px < f.tile_w && py < f.tile_h) {
+                    s = chunk * f.chunk;
+                    s_end = s + f.chunk < f.spp ? s + f.chunk : f.spp;
+                    sum = rt_v3(0.0, 0.0, 0.0);
+                    have = true;
+                }
+            }
+            if (!have) break; /* no work left: this lane retires */
+            rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+        }
+        segs += path.depth_left != 0u ? 1ull : 0ull;
+        rt_path_step(sc, path, stk);
+        if (!path.alive) {
+            sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
+            ++s;
+        }
+    }
+    if (segs) atomicAdd(&counters[1], segs);
+}
+
+/* Sum the chunk partials of each pixel in chunk order; then Color::into_sampled
+ * (color.rs:14-21) unless raw sums were asked for. */
+__global__ void rt_resolve_kernel(const double* __restrict__ partial, double* __restrict__ out,
+                                  unsigned long long npix, uint32_t n_chunks, uint32_t spp, uint32_t out_sum) {
+    unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    RtV3 total = rt_v3(0.0, 0.0, 0.0);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const double* src = partial + ((unsigned long long)c * npix + p) * 3ull;
+        total = total + rt_v3(src[0], src[1], src[2]);
+    }
+    if (!out_sum) total = rt_into_sampled(total, spp);
+    out[p * 3 + 0] = total.x; out[p * 3 + 1] = total.y; out[p * 3 + 2] = total.z;
+}
+
+__global__ void rt_debug_eval_kernel(int fn, const double* a, const double* b, double* out, unsigned long long n) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = a[i], y = b[i], r = 0.0;
+    switch (fn) {
+        case 0: r = x / y; break;
+        case 1: r = rt_sqrt(rt_abs(x)); break;
+        case 2: r = rt_sin(x); break;
+        case 3: r = rt_cos(x); break;
+        case 4: r = rt_acos(x / (rt_abs(x) + 1.0)); break;
+        case 5: r = rt_atan2(x, y); break;
+        case 6: r = rt_log(rt_abs(y)); break;
+        case 7: { RtRng g = rt_rng_pixel_sample(i, (uint32_t)rt_d2u(x), 0u); r = rt_gen_f64(g); } break;
+        case 8: { RtRng g = rt_rng_pixel_sample(i, (uint32_t)rt_d2u(x), 0u); (void)rt_gen_f64(g); r = rt_gen_range(g, -1.0, 1.0); } break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    rt1w::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+
+} // namespace
+
+struct rt1w_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* d_nodes = nullptr; void* d_lights = nullptr; void* d_materials = nullptr;
+    void* d_textures = nullptr; void* d_perlin = nullptr; void* d_images = nullptr;
+    RtSceneView view{};
+    double* d_partial = nullptr; size_t partial_bytes = 0;
+    double* d_out = nullptr; size_t out_bytes = 0;
+    unsigned long long* d_counters = nullptr;
+    int grid = 0;
+};
+
+namespace {
+
+bool upload(void** dst, const void* src, size_t bytes) {
+    *dst = nullptr;
+    size_t alloc = bytes ? bytes : 16;
+    if (!hip_ok(hipMalloc(dst, alloc), "hipMalloc(scene)")) return false;
+    if (bytes && !hip_ok(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(scene)")) return false;
+    return true;
+}
+
+int validate(const rt1w_context* c, const rt1w_render_params* p) {
+    if (!c || !p) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (p->width < 2 || p->height < 2) { rt1w::set_error("width and height must be >= 2 (u,v divide by W-1, H-1; main.rs:968-969)"); return RT1W_ERR_INVALID; }
+    if (p->tile_w == 0 || p->tile_h == 0 || (uint64_t)p->x0 + p->tile_w > p->width || (uint64_t)p->y0 + p->tile_h > p->height) {
+        rt1w::set_error("tile outside the image"); return RT1W_ERR_INVALID;
+    }
+    if (p->spp == 0) { rt1w::set_error("spp must be > 0"); return RT1W_ERR_INVALID; }
+    if ((uint64_t)p->sample_offset + p->spp > 0xFFFFFFFFull) { rt1w::set_error("sample index overflow"); return RT1W_ERR_INVALID; }
+    return RT1W_OK;
+}
+
+int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, rt1w_stats* stats) {
+    RtFrame f;
+    f.width = p->width; f.height = p->height;
+    f.x0 = p->x0; f.y0 = p->y0; f.tile_w = p->tile_w; f.tile_h = p->tile_h;
+    f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth;
+    f.global_seed = p->global_seed;
+    f.chunk = p->chunk ? p->chunk : rt1w_default_chunk(p->tile_w, p->tile_h, p->spp);
+    if (f.chunk > f.spp) f.chunk = f.spp;
+    f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
+    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
+    size_t need = (size_t)npix * f.n_chunks * 3 * sizeof(double);
+    if (need > c->partial_bytes) {
+        if (c->d_partial) (void)hipFree(c->d_partial);
+        c->d_partial = nullptr; c->partial_bytes = 0;
+        if (!hip_ok(hipMalloc((void**)&c->d_partial, need), "hipMalloc(partial sums)")) return RT1W_ERR_NOMEM;
+        c->partial_bytes = need;
+    }
+    unsigned long long init[2] = {(unsigned long long)c->grid * RT_BLOCK, 0ull};
+    if (!hip_ok(hipMemcpyAsync(c->d_counters, init, sizeof init, hipMemcpyHostToDevice, c->stream), "counter init")) return RT1W_ERR_DEVICE;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "counter init sync")) return RT1W_ERR_DEVICE;
+    (void)hipEventRecord(c->ev0, c->stream);
+    hipLaunchKernelGGL(rt_render_kernel, dim3(c->grid), dim3(RT_BLOCK), 0, c->stream, c->view, f, c->d_partial, c->d_counters);
+    {
+        unsigned int rb = 256;
+        unsigned int rg = (unsigned int)((npix + rb - 1) / rb);
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, c->stream, c->d_partial, d_out, npix, f.n_chunks,
+                           f.spp, (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
+    }
+    (void)hipEventRecord(c->ev1, c->stream);
+    if (!hip_ok(hipGetLastError(), "kernel launch")) return RT1W_ERR_DEVICE;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "render kernel")) return RT1W_ERR_DEVICE;
+    if (stats) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        unsigned long long cnt[2] = {0, 0};
+        (void)hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost);
+        stats->paths = npix * f.spp;
+        stats->segments = cnt[1];
+        stats->kernel_ms = ms;
+        stats->chunk = f.chunk; stats->n_chunks = f.n_chunks;
+        stats->grid = (uint32_t)c->grid; stats->block = RT_BLOCK;
+    }
+    return RT1W_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t rt1w_default_chunk(uint32_t tile_w, uint32_t tile_h, uint32_t spp) {
+    /* aim for >= ~4M work items so that every resident lane gets >= 16 of them
+     * (tail of the persistent loop ~ 1/32 of the run), but never split below 8 samples */
+    const uint64_t target_items = 4u << 20;
+    uint64_t pixels = (uint64_t)tile_w * tile_h;
+    if (pixels == 0 || spp == 0) return 1;
+    uint64_t n_chunks = (target_items + pixels - 1) / pixels;
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > spp) n_chunks = spp;
+    uint32_t chunk = (uint32_t)((spp + n_chunks - 1) / n_chunks);
+    if (chunk < 8u) chunk = spp < 8u ? spp : 8u;
+    return chunk;
+}
+
+int rt1w_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) {
+    if (!s || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { rt1w::set_error("scene not committed"); return RT1W_ERR_STATE; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        rt1w::set_error("no HIP device: librt1w has no CPU render path"); return RT1W_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) { rt1w::set_error("bad device id"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(device_id), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    rt1w_context* c = new (std::nothrow) rt1w_context();
+    if (!c) { rt1w::set_error("out of memory"); return RT1W_ERR_NOMEM; }
+    c->device = device_id;
+    bool ok = hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") && hip_ok(hipEventCreate(&c->ev0), "hipEventCreate") &&
+              hip_ok(hipEventCreate(&c->ev1), "hipEventCreate") &&
+              upload(&c->d_nodes, s->flat_nodes.data(), s->flat_nodes.size() * sizeof(RtNode)) &&
+              upload(&c->d_lights, s->flat_lights.data(), s->flat_lights.size() * sizeof(RtNode)) &&
+              upload(&c->d_materials, s->materials.data(), s->materials.size() * sizeof(RtMaterial)) &&
+              upload(&c->d_textures, s->textures.data(), s->textures.size() * sizeof(RtTexture)) &&
+              upload(&c->d_perlin, s->perlin.data(), s->perlin.size() * sizeof(RtPerlin)) &&
+              upload(&c->d_images, s->images.data(), s->images.size()) &&
+              hip_ok(hipMalloc((void**)&c->d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(counters)");
+    if (!ok) { rt1w_context_destroy(c); return RT1W_ERR_DEVICE; }
+    RtSceneView& v = c->view;
+    v.nodes = (const RtNode*)c->d_nodes; v.lights = (const RtNode*)c->d_lights;
+    v.materials = (const RtMaterial*)c->d_materials; v.textures = (const RtTexture*)c->d_textures;
+    v.perlin = (const RtPerlin*)c->d_perlin; v.images = (const uint8_t*)c->d_images;
+    v.root = s->flat_root; v.n_nodes = (uint32_t)s->flat_nodes.size(); v.n_lights = (uint32_t)s->flat_lights.size();
+    v.n_materials = (uint32_t)s->materials.size(); v.n_textures = (uint32_t)s->textures.size(); v.pad = 0;
+    v.camera = s->camera; v.background = s->background;
+    /* persistent grid: as many blocks as are resident at once */
+    hipDeviceProp_t prop;
+    int per_cu = 0;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties") ||
+        !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel, RT_BLOCK, 0), "occupancy query")) {
+        rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+    }
+    if (per_cu < 1) per_cu = 1;
+    c->grid = prop.multiProcessorCount * per_cu;
+    *out = c;
+    return RT1W_OK;
+}
+
+void rt1w_context_destroy(rt1w_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images,
+                    c->d_partial, c->d_out, c->d_counters};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out_rgb, rt1w_stats* stats) {
+    int rc = validate(c, p);
+    if (rc < 0) return rc;
+    if (!d_out_rgb) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = render_common(c, p, (double*)d_out_rgb, stats);
+    if (rc == RT1W_OK && stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, rt1w_stats* stats) {
+    int rc = validate(c, p);
+    if (rc < 0) return rc;
+    if (!out_rgb) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    auto t0 = std::chrono::steady_clock::now();
+    size_t bytes = (size_t)p->tile_w * p->tile_h * 3 * sizeof(double);
+    if (bytes > c->out_bytes) {
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_out = nullptr; c->out_bytes = 0;
+        if (!hip_ok(hipMalloc((void**)&c->d_out, bytes), "hipMalloc(framebuffer)")) return RT1W_ERR_NOMEM;
+        c->out_bytes = bytes;
+    }
+    rc = render_common(c, p, c->d_out, stats);
+    if (rc < 0) return rc;
+    if (!hip_ok(hipMemcpy(out_rgb, c->d_out, bytes, hipMemcpyDeviceToHost), "framebuffer copy")) return RT1W_ERR_DEVICE;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT1W_OK;
+}
+
+int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, double* out, uint64_t n) {
+    if (!c || !a || !b || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (n == 0) return RT1W_OK;
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    size_t bytes = (size_t)n * sizeof(double);
+    int rc = RT1W_OK;
+    if (!hip_ok(hipMalloc((void**)&da, bytes), "hipMalloc") || !hip_ok(hipMalloc((void**)&db, bytes), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&dout, bytes), "hipMalloc")) rc = RT1W_ERR_NOMEM;
+    if (rc == RT1W_OK) {
+        (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(rt_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fn, da, db, dout, (unsigned long long)n);
+        if (!hip_ok(hipStreamSynchronize(c->stream), "debug kernel")) rc = RT1W_ERR_DEVICE;
+        else (void)hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    }
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+} /* extern "C" */

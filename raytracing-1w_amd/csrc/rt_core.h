@@ -1,0 +1,664 @@
+/* rt_core.h -- the per-pixel sample loop and the iterative `ray_color`, over the
+ * flattened scene (rt_flat.h).  This is the text the HIP kernel is built from.
+ * It is also compiled for the host by oracle/oracle_flat.cpp, as TEST
+ * infrastructure only (sanitizer builds, CPU-side checks of the flattener);
+ * the shipped library has no CPU render path.
+ *
+ * Reference map (paths under /root/reference/src):
+ *   rt_path_begin   main.rs:964-971 (seed, jitter, Camera::get_ray camera.rs:61-73)
+ *   rt_path_step    main.rs:51-116 / :118-190, recursion unrolled into
+ *                   L += beta*emitted ; beta *= att*spdf/pdf (or att)
+ *   rt_traverse     bvh.rs:25-50 + aabb.rs:13-32 + every leaf `hit`
+ *   rt_finish_hit   HitRecord::new hittable.rs:21-46 and the wrapper fix-ups
+ *                   hittable.rs:206-226 (Translate), :237-279 (RotateY), :287-292 (FlipFace)
+ *   rt_scatter...   material.rs, constant_medium.rs:36-51, pdf.rs, onb.rs, math.rs
+ *   rt_texture      texture.rs:40-89, perlin.rs:46-106
+ *
+ * Traversal order is the reference's: depth first, left child before right,
+ * with the running closest t as t_max (bvh.rs:38-47 is exactly that, because
+ * the t_max handed to the right child is the left child's hit).  This matters
+ * for results, not only speed: ConstantMedium::hit draws a random number
+ * inside the traversal (constant_medium.rs:85) and ties in t go to the child
+ * tested later.
+ */
+#ifndef RT1W_CORE_H
+#define RT1W_CORE_H
+
+#include "rt_flat.h"
+
+#define RT_POP_FLAG 0x80000000u
+
+struct RtRay { RtV3 o, d; double time; };
+struct RtRayOD { RtV3 o, d; };
+
+/* HitRecord, hittable.rs:10-18 (material as table index) */
+struct RtHit {
+    RtV3 p, n;
+    double t, u, v;
+    uint32_t mat;
+    bool front;
+};
+
+struct RtPath {
+    RtRay ray;
+    RtV3 beta;      /* product of (attenuation*scattering_pdf/pdf) so far */
+    RtV3 radiance;  /* sum of beta*emitted so far */
+    RtRng rng;
+    uint32_t depth_left;
+    bool alive;
+};
+
+/* ------------------------------------------------------------ geometry -- */
+
+RT_HD RtV3 rt_at(RtV3 o, RtV3 d, double t) { return o + t * d; } /* ray.rs:12-14 */
+
+/* AABB::hit aabb.rs:13-32; inv = 1/direction is the same value at every node of
+ * one ray, so it is computed once per ray-space instead of per node. */
+RT_HD bool rt_aabb_hit(const double* bb, RtV3 o, RtV3 inv, double t_min, double t_max) {
+#define RT_SLAB(minv, maxv, ov, iv)                      \
+    {                                                    \
+        double t0 = ((minv) - (ov)) * (iv);              \
+        double t1 = ((maxv) - (ov)) * (iv);              \
+        if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
+        t_min = t0 > t_min ? t0 : t_min;                 \
+        t_max = t1 < t_max ? t1 : t_max;                 \
+        if (t_max <= t_min) return false;                \
+    }
+    RT_SLAB(bb[0], bb[3], o.x, inv.x)
+    RT_SLAB(bb[1], bb[4], o.y, inv.y)
+    RT_SLAB(bb[2], bb[5], o.z, inv.z)
+#undef RT_SLAB
+    return true;
+}
+
+/* Sphere::hit sphere.rs:31-48 / MovingSphere::hit moving_sphere.rs:38-55: the root only */
+RT_HD bool rt_sphere_root(RtV3 center, double radius, RtV3 o, RtV3 d, double t_min, double t_max,
+                          double& root_out) {
+    RtV3 oc = o - center;
+    double a = rt_mag2(d);
+    double half_b = rt_dot(oc, d);
+    double c = rt_mag2(oc) - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd = rt_sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    root_out = root;
+    return true;
+}
+/* MovingSphere::center moving_sphere.rs:23-26 */
+RT_HD RtV3 rt_msphere_center(const RtNode& nd, double time) {
+    RtV3 c0 = rt_v3(nd.d[0], nd.d[1], nd.d[2]), c1 = rt_v3(nd.d[3], nd.d[4], nd.d[5]);
+    return c0 + ((time - nd.d[6]) / (nd.d[7] - nd.d[6])) * (c1 - c0);
+}
+/* XYRect/XZRect/YZRect::hit aarect.rs:46-56,84-94,152-162: t and the in-bounds test.
+ * (oa,da) is the axis normal to the plane, (ob,db),(oc,dc) the two in-plane axes. */
+RT_HD bool rt_rect_t(const RtNode& nd, double oa, double da, double ob, double db, double oc,
+                     double dc, double t_min, double t_max, double& t_out) {
+    double t = (nd.d[4] - oa) / da;
+    if (t < t_min || t > t_max) return false;
+    double b = ob + t * db;
+    double c = oc + t * dc;
+    if (b < nd.d[0] || b > nd.d[1] || c < nd.d[2] || c > nd.d[3]) return false;
+    t_out = t;
+    return true;
+}
+RT_HD bool rt_prim_t(const RtNode& nd, RtV3 o, RtV3 d, double time, double t_min, double t_max,
+                     double& t) {
+    switch (nd.kind) {
+        case RT_SPHERE:
+            return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t);
+        case RT_MSPHERE:
+            return rt_sphere_root(rt_msphere_center(nd, time), nd.d[8], o, d, t_min, t_max, t);
+        case RT_XY: return rt_rect_t(nd, o.z, d.z, o.x, d.x, o.y, d.y, t_min, t_max, t);
+        case RT_XZ: return rt_rect_t(nd, o.y, d.y, o.x, d.x, o.z, d.z, t_min, t_max, t);
+        case RT_YZ: return rt_rect_t(nd, o.x, d.x, o.y, d.y, o.z, d.z, t_min, t_max, t);
+        default: return false;
+    }
+}
+
+/* Translate::hit hittable.rs:207-211 / RotateY::hit hittable.rs:238-251: ray into the wrapper's space */
+RT_HD RtRayOD rt_scope_in(const RtNode& s, RtRayOD r) {
+    if (s.kind == RT_TRANSLATE) {
+        r.o = r.o - rt_v3(s.d[0], s.d[1], s.d[2]);
+    } else if (s.kind == RT_ROTATE_Y) {
+        double sn = s.d[0], cs = s.d[1];
+        RtV3 o = r.o, d = r.d;
+        r.o.x = cs * o.x - sn * o.z;
+        r.o.z = sn * o.x + cs * o.z;
+        r.d.x = cs * d.x - sn * d.z;
+        r.d.z = sn * d.x + cs * d.z;
+    }
+    return r;
+}
+/* the way back out: hittable.rs:215-225, :255-278, :288-291.  `inner` is the ray in
+ * the wrapper's space (`moved` / `rotated_r`): both re-run HitRecord::new with it,
+ * taking the child's already-forwarded normal as "outward" (reference quirk Q5). */
+RT_HD void rt_scope_out(const RtNode& s, const RtRayOD& inner, RtHit& h) {
+    if (s.kind == RT_TRANSLATE) {
+        h.p = h.p + rt_v3(s.d[0], s.d[1], s.d[2]);
+        bool front = rt_dot(inner.d, h.n) < 0.0;
+        h.n = front ? h.n : -h.n;
+        h.front = front;
+    } else if (s.kind == RT_ROTATE_Y) {
+        double sn = s.d[0], cs = s.d[1];
+        RtV3 p = h.p, n = h.n;
+        p.x = cs * h.p.x + sn * h.p.z;
+        p.z = -sn * h.p.x + cs * h.p.z;
+        n.x = cs * h.n.x + sn * h.n.z;
+        n.z = -sn * h.n.x + cs * h.n.z;
+        bool front = rt_dot(inner.d, n) < 0.0;
+        h.p = p;
+        h.n = front ? n : -n;
+        h.front = front;
+    } else { /* RT_FLIP */
+        h.front = !h.front;
+    }
+}
+
+/* wrapper chain above a primitive, outermost first (depth <= RT_MAX_SCOPE_DEPTH) */
+struct RtChain { uint32_t s0, s1, s2; };
+RT_HD RtChain rt_chain(const RtNode* nodes, uint32_t scope) {
+    RtChain c; c.s0 = c.s1 = c.s2 = RT_NONE;
+    while (scope != RT_NONE) {
+        c.s2 = c.s1; c.s1 = c.s0; c.s0 = scope;
+        scope = nodes[scope].b;
+    }
+    return c;
+}
+RT_HD RtRayOD rt_ray_in_scope(const RtNode* nodes, uint32_t scope, RtRayOD world) {
+    if (scope == RT_NONE) return world;
+    RtChain c = rt_chain(nodes, scope);
+    RtRayOD r = rt_scope_in(nodes[c.s0], world);
+    if (c.s1 != RT_NONE) r = rt_scope_in(nodes[c.s1], r);
+    if (c.s2 != RT_NONE) r = rt_scope_in(nodes[c.s2], r);
+    return r;
+}
+
+/* sphere_uv math.rs:67-71 */
+RT_HD void rt_sphere_uv(RtV3 p, double& u, double& v) {
+    double theta = rt_acos(-p.y);
+    double phi = rt_atan2(-p.z, p.x) + RT_PI;
+    u = phi / (2.0 * RT_PI);
+    v = theta / RT_PI;
+}
+
+/* The leaf's own HitRecord (sphere.rs:50-62, moving_sphere.rs:57-69, aarect.rs:58-71,
+ * 96-109,164-177, constant_medium.rs:98-106) in the leaf's space.  u,v are only
+ * evaluated when the material's texture reads them (image texture); they are
+ * unobservable otherwise. */
+RT_HD void rt_leaf_record(const RtNode& nd, const RtRayOD& r, double time, double t, bool want_uv,
+                          RtHit& h) {
+    h.t = t; h.u = 0.0; h.v = 0.0; h.mat = nd.mat;
+    h.p = rt_at(r.o, r.d, t);
+    RtV3 on;
+    if (nd.kind == RT_SPHERE || nd.kind == RT_MSPHERE) {
+        if (nd.kind == RT_SPHERE) on = (h.p - rt_v3(nd.d[0], nd.d[1], nd.d[2])) / nd.d[3];
+        else on = (h.p - rt_msphere_center(nd, time)) / nd.d[8];
+        if (want_uv) rt_sphere_uv(on, h.u, h.v);
+    } else if (nd.kind == RT_MEDIUM) {
+        h.n = rt_v3(1.0, 0.0, 0.0);
+        h.front = true;
+        return;
+    } else {
+        double b, c;
+        if (nd.kind == RT_XY) { on = rt_v3(0.0, 0.0, 1.0); b = r.o.x + t * r.d.x; c = r.o.y + t * r.d.y; }
+        else if (nd.kind == RT_XZ) { on = rt_v3(0.0, 1.0, 0.0); b = r.o.x + t * r.d.x; c = r.o.z + t * r.d.z; }
+        else { on = rt_v3(1.0, 0.0, 0.0); b = r.o.y + t * r.d.y; c = r.o.z + t * r.d.z; }
+        if (want_uv) {
+            h.u = (b - nd.d[0]) / (nd.d[1] - nd.d[0]);
+            h.v = (c - nd.d[2]) / (nd.d[3] - nd.d[2]);
+        }
+    }
+    /* HitRecord::new hittable.rs:30-35 */
+    bool front = rt_dot(r.d, on) < 0.0;
+    h.n = front ? on : -on;
+    h.front = front;
+}
+
+/* Full hit record of the winning leaf: leaf record in its own space, then the
+ * wrapper fix-ups innermost to outermost. */
+RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t prim, uint32_t scope,
+                         double t, RtHit& h) {
+    const RtNode* nodes = sc.nodes;
+    RtNode nd = nodes[prim];
+    bool want_uv = (sc.materials[nd.mat].kind & RT_MAT_NEEDS_UV) != 0u;
+    RtRayOD r0; r0.o = world.o; r0.d = world.d;
+    if (scope == RT_NONE) {
+        rt_leaf_record(nd, r0, world.time, t, want_uv, h);
+        return;
+    }
+    RtChain c = rt_chain(nodes, scope);
+    RtRayOD r1 = rt_scope_in(nodes[c.s0], r0);
+    RtRayOD r2 = r1, r3 = r1;
+    if (c.s1 != RT_NONE) { r2 = rt_scope_in(nodes[c.s1], r1); r3 = r2; }
+    if (c.s2 != RT_NONE) r3 = rt_scope_in(nodes[c.s2], r2);
+    rt_leaf_record(nd, r3, world.time, t, want_uv, h);
+    if (c.s2 != RT_NONE) rt_scope_out(nodes[c.s2], r3, h);
+    if (c.s1 != RT_NONE) rt_scope_out(nodes[c.s1], r2, h);
+    rt_scope_out(nodes[c.s0], r1, h);
+}
+
+/* ----------------------------------------------------------- traversal -- */
+
+RT_HD RtV3 rt_inv3(RtV3 d) { return rt_v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+
+/* Closest hit of the subtree `root` for `world` (a ray in the subtree's outer
+ * space) within [t_min, t_max].  MEDIA=false is the flavour used for a
+ * ConstantMedium's boundary, where only t is consumed (constant_medium.rs:62-69). */
+template <bool MEDIA, class Stack>
+RT_HD bool rt_traverse(const RtSceneView& sc, uint32_t root, const RtRay& world, double t_min,
+                       double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
+                       uint32_t& out_scope) {
+    const RtNode* nodes = sc.nodes;
+    RtRayOD w; w.o = world.o; w.d = world.d;
+    RtRayOD cur = w;
+    RtV3 inv = rt_inv3(cur.d);
+    uint32_t scope = RT_NONE;
+    double best_t = t_max;
+    uint32_t best_prim = RT_NONE, best_scope = RT_NONE;
+    const int base = stk.sp;
+    stk.push(root);
+    while (stk.sp > base) {
+        uint32_t e = stk.pop();
+        if (e & RT_POP_FLAG) {
+            /* leaving a wrapper: back to the parent's ray (recomputed from the
+             * outer ray by the same operations that produced it, hence the same bits) */
+            scope = nodes[e & ~RT_POP_FLAG].b;
+            cur = rt_ray_in_scope(nodes, scope, w);
+            inv = rt_inv3(cur.d);
+            continue;
+        }
+        const RtNode& nd = nodes[e];
+        uint32_t kind = nd.kind;
+        if (kind <= RT_BVH1) {
+            if (rt_aabb_hit(nd.d, cur.o, inv, t_min, best_t)) {
+                if (kind == RT_BVH2) stk.push(nd.b);
+                stk.push(nd.a);
+            }
+        } else if (kind <= RT_YZ) {
+            double t;
+            if (rt_prim_t(nd, cur.o, cur.d, world.time, t_min, best_t, t)) {
+                best_t = t; best_prim = e; best_scope = scope;
+            }
+        } else if (kind <= RT_FLIP) {
+            stk.push(e | RT_POP_FLAG);
+            scope = e;
+            if (kind != RT_FLIP) {
+                cur = rt_scope_in(nd, cur);
+                if (kind == RT_ROTATE_Y) inv = rt_inv3(cur.d);
+            }
+            stk.push(nd.a);
+        } else if (MEDIA && kind == RT_MEDIUM) {
+            /* ConstantMedium::hit constant_medium.rs:58-113 */
+            RtRay br; br.o = cur.o; br.d = cur.d; br.time = world.time;
+            double t1, t2; uint32_t p_, s_;
+            if (!rt_traverse<false>(sc, nd.a, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_)) continue;
+            if (!rt_traverse<false>(sc, nd.a, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_)) continue;
+            double rec1 = rt_max(t1, t_min);
+            double rec2 = rt_min(t2, best_t);
+            if (rec1 >= rec2) continue;
+            rec1 = rt_max(rec1, 0.0);
+            double ray_length = rt_mag(cur.d);
+            double distance_inside_boundary = (rec2 - rec1) * ray_length;
+            double hit_distance = nd.d[0] * rt_log(rt_gen_f64(rng));
+            if (hit_distance > distance_inside_boundary) continue;
+            best_t = rec1 + hit_distance / ray_length;
+            best_prim = e; best_scope = scope;
+        }
+    }
+    out_t = best_t; out_prim = best_prim; out_scope = best_scope;
+    return best_prim != RT_NONE;
+}
+
+/* ------------------------------------------------------------ textures -- */
+
+/* Perlin::noise perlin.rs:46-72 + perlin_interp :88-106 */
+RT_HD double rt_perlin_noise(const RtPerlin& pl, RtV3 p) {
+    double fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
+    double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    /* `as isize` saturates; & 255 afterwards */
+    int64_t i = (fx >= 9.2e18) ? INT64_MAX : (fx <= -9.2e18) ? INT64_MIN : (fx != fx ? 0 : (int64_t)fx);
+    int64_t j = (fy >= 9.2e18) ? INT64_MAX : (fy <= -9.2e18) ? INT64_MIN : (fy != fy ? 0 : (int64_t)fy);
+    int64_t k = (fz >= 9.2e18) ? INT64_MAX : (fz <= -9.2e18) ? INT64_MIN : (fz != fz ? 0 : (int64_t)fz);
+    double uu = u * u * (3.0 - 2.0 * u);
+    double vv = v * v * (3.0 - 2.0 * v);
+    double ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                /* wrapping add like the release build of the reference */
+                uint32_t ii = (uint32_t)(((uint64_t)i + (uint64_t)di) & 255u);
+                uint32_t jj = (uint32_t)(((uint64_t)j + (uint64_t)dj) & 255u);
+                uint32_t kk = (uint32_t)(((uint64_t)k + (uint64_t)dk) & 255u);
+                uint32_t idx = pl.perm_x[ii] ^ pl.perm_y[jj] ^ pl.perm_z[kk];
+                RtV3 c = rt_v3(pl.ranvec[idx * 3 + 0], pl.ranvec[idx * 3 + 1], pl.ranvec[idx * 3 + 2]);
+                double fi = (double)di, fj = (double)dj, fk = (double)dk;
+                RtV3 weight_v = rt_v3(u - fi, v - fj, w - fk);
+                accum += (fi * uu + (1.0 - fi) * (1.0 - uu)) * (fj * vv + (1.0 - fj) * (1.0 - vv)) *
+                         (fk * ww + (1.0 - fk) * (1.0 - ww)) * rt_dot(c, weight_v);
+            }
+    return accum;
+}
+/* Perlin::turb perlin.rs:74-86 */
+RT_HD double rt_perlin_turb(const RtPerlin& pl, RtV3 p, int depth) {
+    double accum = 0.0, weight = 1.0;
+    RtV3 temp_p = p;
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * rt_perlin_noise(pl, temp_p);
+        weight *= 0.5;
+        temp_p = temp_p * 2.0;
+    }
+    return rt_abs(accum);
+}
+/* `x as u32` of Rust: saturating, NaN -> 0 */
+RT_HD uint32_t rt_as_u32(double x) {
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 4294967295u;
+    return (uint32_t)x;
+}
+/* Texture::value texture.rs:40-89 */
+RT_HD RtV3 rt_texture(const RtSceneView& sc, uint32_t tex, double u, double v, RtV3 p) {
+    for (;;) {
+        const RtTexture& t = sc.textures[tex];
+        if (t.kind == RT_TEX_CHECKER) {
+            double sines = rt_sin(10.0 * p.x) * rt_sin(10.0 * p.y) * rt_sin(10.0 * p.z);
+            tex = (sines < 0.0) ? t.a : t.b;
+            continue;
+        }
+        if (t.kind == RT_TEX_SOLID) return rt_v3(t.d[0], t.d[1], t.d[2]);
+        if (t.kind == RT_TEX_NOISE) {
+            double s = 1.0 * 0.5 * (1.0 + rt_sin(t.d[0] * p.z + 10.0 * rt_perlin_turb(sc.perlin[t.a], p, 7)));
+            return rt_v3(s, s, s);
+        }
+        /* RT_TEX_IMAGE texture.rs:67-88 */
+        double uc = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+        double vc = 1.0 - (v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v));
+        uint32_t i = rt_as_u32(uc * (double)t.a);
+        uint32_t j = rt_as_u32(vc * (double)t.b);
+        i = i < t.a - 1u ? i : t.a - 1u;
+        j = j < t.b - 1u ? j : t.b - 1u;
+        const uint8_t* px = sc.images + t.c + ((size_t)j * t.a + i) * 3u;
+        const double COLOR_SCALE = 1.0 / 255.0;
+        return rt_v3((double)px[0] * COLOR_SCALE, (double)px[1] * COLOR_SCALE, (double)px[2] * COLOR_SCALE);
+    }
+}
+
+/* ------------------------------------------------------------ samplers -- */
+
+/* math.rs:6-18 */
+RT_HD RtV3 rt_random_in_unit_sphere(RtRng& rng) {
+    for (;;) {
+        double x = rt_gen_range(rng, -1.0, 1.0);
+        double y = rt_gen_range(rng, -1.0, 1.0);
+        double z = rt_gen_range(rng, -1.0, 1.0);
+        RtV3 v = rt_v3(x, y, z);
+        if (rt_mag2(v) < 1.0) return v;
+    }
+}
+/* math.rs:30-37 */
+RT_HD RtV3 rt_random_in_unit_disk(RtRng& rng) {
+    for (;;) {
+        double x = rt_gen_range(rng, -1.0, 1.0);
+        double y = rt_gen_range(rng, -1.0, 1.0);
+        RtV3 p = rt_v3(x, y, 0.0);
+        if (rt_mag2(p) < 1.0) return p;
+    }
+}
+/* math.rs:39-49 */
+RT_HD RtV3 rt_random_cosine_direction(RtRng& rng) {
+    double r1 = rt_gen_f64(rng);
+    double r2 = rt_gen_f64(rng);
+    double z = rt_sqrt(1.0 - r2);
+    double phi = 2.0 * RT_PI * r1;
+    double s, c;
+    rt_sincos(phi, s, c);
+    double sr2 = rt_sqrt(r2);
+    return rt_v3(c * sr2, s * sr2, z);
+}
+/* math.rs:51-65 */
+RT_HD RtV3 rt_random_to_sphere(double radius, double distance_squared, RtRng& rng) {
+    double r1 = rt_gen_f64(rng);
+    double r2 = rt_gen_f64(rng);
+    double z = 1.0 + r2 * (rt_sqrt(1.0 - radius * radius / distance_squared) - 1.0);
+    double phi = 2.0 * RT_PI * r1;
+    double s, c;
+    rt_sincos(phi, s, c);
+    double q = rt_sqrt(1.0 - z * z);
+    return rt_v3(c * q, s * q, z);
+}
+
+/* Onb onb.rs:13-28 */
+struct RtOnb { RtV3 u, v, w; };
+RT_HD RtOnb rt_onb_from_w(RtV3 n) {
+    RtOnb o;
+    o.w = rt_normalize(n);
+    RtV3 a = (rt_abs(o.w.x) > 0.9) ? rt_v3(0.0, 1.0, 0.0) : rt_v3(1.0, 0.0, 0.0);
+    o.v = rt_normalize(rt_cross(o.w, a));
+    o.u = rt_cross(o.w, o.v);
+    return o;
+}
+RT_HD RtV3 rt_onb_local(const RtOnb& o, RtV3 a) { return o.u * a.x + o.v * a.y + o.w * a.z; }
+
+/* ---------------------------------------------------------------- lights -- */
+
+/* Hittable::pdf_value of one light: XZRect aarect.rs:119-138, Sphere sphere.rs:72-90,
+ * anything else the trait default 0.0 (hittable.rs:66-68) */
+RT_HD double rt_light_pdf_value(const RtNode& l, RtV3 o, RtV3 v) {
+    if (l.kind == RT_XZ) {
+        double t;
+        if (!rt_rect_t(l, o.y, v.y, o.x, v.x, o.z, v.z, 0.001, RT_INF, t)) return 0.0;
+        RtV3 on = rt_v3(0.0, 1.0, 0.0);
+        RtV3 normal = (rt_dot(v, on) < 0.0) ? on : -on;
+        double area = (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]);
+        double distance_squared = t * t * rt_mag2(v);
+        double cosine = rt_abs(rt_dot(v, normal) / rt_mag(v));
+        return distance_squared / (cosine * area);
+    }
+    if (l.kind == RT_SPHERE) {
+        double t;
+        RtV3 center = rt_v3(l.d[0], l.d[1], l.d[2]);
+        if (!rt_sphere_root(center, l.d[3], o, v, 0.001, RT_INF, t)) return 0.0;
+        double cos_theta_max = rt_sqrt(1.0 - l.d[3] * l.d[3] / rt_mag2(center - o));
+        double solid_angle = 2.0 * RT_PI * (1.0 - cos_theta_max);
+        return 1.0 / solid_angle;
+    }
+    return 0.0;
+}
+/* Hittable::random of one light: aarect.rs:140-147, sphere.rs:92-99, default (1,0,0) */
+RT_HD RtV3 rt_light_random(const RtNode& l, RtV3 o, RtRng& rng) {
+    if (l.kind == RT_XZ) {
+        double x = rt_gen_range(rng, l.d[0], l.d[1]);
+        double z = rt_gen_range(rng, l.d[2], l.d[3]);
+        return rt_v3(x, l.d[4], z) - o;
+    }
+    if (l.kind == RT_SPHERE) {
+        RtV3 direction = rt_v3(l.d[0], l.d[1], l.d[2]) - o;
+        double distance_squared = rt_mag2(direction);
+        RtOnb uvw = rt_onb_from_w(direction);
+        return rt_onb_local(uvw, rt_random_to_sphere(l.d[3], distance_squared, rng));
+    }
+    return rt_v3(1.0, 0.0, 0.0);
+}
+/* impl Hittable for [T]: pdf_value hittable.rs:144-150 */
+RT_HD double rt_lights_pdf_value(const RtSceneView& sc, RtV3 o, RtV3 v) {
+    double weight = 1.0 / (double)sc.n_lights;
+    double sum = 0.0;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) sum = sum + weight * rt_light_pdf_value(sc.lights[i], o, v);
+    return sum;
+}
+
+/* ------------------------------------------------------------ materials -- */
+
+RT_HD RtV3 rt_reflect(RtV3 v, RtV3 n) { return v - 2.0 * rt_dot(v, n) * n; } /* material.rs:94-96 */
+RT_HD RtV3 rt_refract(RtV3 uv, RtV3 n, double etai_over_etat) {               /* material.rs:114-119 */
+    double cos_theta = rt_min(rt_dot(-uv, n), 1.0);
+    RtV3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    RtV3 r_out_parallel = -rt_sqrt(rt_abs(1.0 - rt_mag2(r_out_perp))) * n;
+    return r_out_perp + r_out_parallel;
+}
+RT_HD double rt_reflectance(double cosine, double ref_idx) {                  /* material.rs:121-125 */
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0 - r0) * rt_pow5(1.0 - cosine);
+}
+
+/* --------------------------------------------------------------- camera -- */
+
+/* main.rs:964-971 + Camera::get_ray camera.rs:61-73 */
+RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, uint32_t j,
+                         uint32_t sample, RtPath& p) {
+    p.rng = rt_rng_pixel_sample((uint64_t)j * f.width + i, sample, f.global_seed);
+    double u = ((double)i + rt_gen_f64(p.rng)) / (double)(f.width - 1u);
+    double v = ((double)j + rt_gen_f64(p.rng)) / (double)(f.height - 1u);
+    const RtCamera& c = sc.camera;
+    RtV3 rd = c.lens_radius * rt_random_in_unit_disk(p.rng);
+    RtV3 offset = c.u * rd.x + c.v * rd.y;
+    p.ray.o = c.origin + offset;
+    p.ray.d = c.lower_left_corner + u * c.horizontal + v * c.vertical - c.origin - offset;
+    p.ray.time = rt_gen_range(p.rng, c.time0, c.time1);
+    p.beta = rt_v3(1.0, 1.0, 1.0);
+    p.radiance = rt_v3(0.0, 0.0, 0.0);
+    p.depth_left = f.max_depth;
+    p.alive = true;
+}
+
+/* ------------------------------------------------------------ integrator -- */
+
+/* One level of ray_color (main.rs:51-116; with no lights :118-190).  The
+ * recursion  L = emitted + W (.) L'/pdf  is carried as  radiance += beta (.) emitted,
+ * beta = beta (.) W / pdf.  Every terminal adds beta (.) value -- including the zero
+ * of depth exhaustion (main.rs:59-61) -- so a non-finite beta poisons the sample
+ * exactly as it does through the reference's multiplications. */
+template <class Stack>
+RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
+    if (p.depth_left == 0u) {
+        p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
+        p.alive = false;
+        return;
+    }
+    double t; uint32_t prim, scope;
+    if (!rt_traverse<true>(sc, sc.root, p.ray, 0.001, RT_INF, p.rng, stk, t, prim, scope)) {
+        p.radiance = p.radiance + rt_mul(p.beta, sc.background);
+        p.alive = false;
+        return;
+    }
+    RtHit h;
+    rt_finish_hit(sc, p.ray, prim, scope, t, h);
+    const RtMaterial& m = sc.materials[h.mat];
+    uint32_t mk = m.kind & 0xFFu;
+
+    /* emitted: DiffuseLight material.rs:168-181 (front face only); every other
+     * material returns the default (0,0,0) (material.rs:40-49), whose addition in
+     * main.rs:92 changes nothing, so it is not carried.  In this reference the
+     * emitting material never scatters, so a path's radiance is beta (.) its
+     * terminal value (light, background, or the zero of depth exhaustion). */
+    if (mk == RT_MAT_DIFFUSE_LIGHT) {
+        RtV3 emitted = h.front ? rt_texture(sc, m.tex, h.u, h.v, h.p) : rt_v3(0.0, 0.0, 0.0);
+        p.radiance = p.radiance + rt_mul(p.beta, emitted);
+        p.alive = false; /* DiffuseLight::scatter -> None, main.rs:110-112 */
+        return;
+    }
+
+    if (mk == RT_MAT_LAMBERTIAN) {
+        /* Lambertian::scatter material.rs:71-80 -> ScatterKind::Pdf(CosinePdf) */
+        RtV3 attenuation = rt_texture(sc, m.tex, h.u, h.v, h.p);
+        RtOnb uvw = rt_onb_from_w(h.n);
+        RtV3 dir;
+        double pdf;
+        if (sc.n_lights > 0u) {
+            /* MixturePdf::generate pdf.rs:62-68, p0 = HittablePdf{lights} */
+            if (rt_gen_bool(p.rng)) {
+                uint32_t li = rt_gen_below(p.rng, sc.n_lights); /* choose, hittable.rs:153 */
+                dir = rt_light_random(sc.lights[li], h.p, p.rng);
+            } else {
+                dir = rt_onb_local(uvw, rt_random_cosine_direction(p.rng)); /* pdf.rs:42-44 */
+            }
+            /* MixturePdf::value pdf.rs:58-60 */
+            double p0 = rt_lights_pdf_value(sc, h.p, dir);
+            double p1 = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0); /* pdf.rs:37-40 */
+            pdf = 0.5 * p0 + 0.5 * p1;
+        } else {
+            dir = rt_onb_local(uvw, rt_random_cosine_direction(p.rng));
+            pdf = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0);
+        }
+        /* Lambertian::scattering_pdf material.rs:82-91 */
+        double spdf = rt_max(rt_dot(h.n, rt_normalize(dir)) / RT_PI, 0.0);
+        p.beta = rt_mul(p.beta, attenuation * spdf) / pdf;
+        p.ray.o = h.p; p.ray.d = dir;
+        p.ray.time = h.t; /* main.rs:86: time = hit_record.t (reference quirk Q1) */
+    } else if (mk == RT_MAT_METAL) {
+        /* Metal::scatter material.rs:99-111 */
+        RtV3 reflected = rt_reflect(rt_normalize(p.ray.d), h.n);
+        RtV3 dir = reflected + m.d[3] * rt_random_in_unit_sphere(p.rng);
+        p.beta = rt_mul(p.beta, rt_v3(m.d[0], m.d[1], m.d[2]));
+        p.ray.o = h.p; p.ray.d = dir;
+    } else if (mk == RT_MAT_DIELECTRIC) {
+        /* Dielectric::scatter material.rs:133-160 */
+        double refraction_ratio = h.front ? 1.0 / m.d[0] : m.d[0];
+        RtV3 unit_direction = rt_normalize(p.ray.d);
+        double cos_theta = rt_min(rt_dot(-unit_direction, h.n), 1.0);
+        double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        RtV3 dir;
+        if (cannot_refract || rt_reflectance(cos_theta, refraction_ratio) > rt_gen_f64(p.rng))
+            dir = rt_reflect(unit_direction, h.n);
+        else
+            dir = rt_refract(unit_direction, h.n, refraction_ratio);
+        p.beta = rt_mul(p.beta, rt_v3(1.0, 1.0, 1.0));
+        p.ray.o = h.p; p.ray.d = dir;
+    } else if (mk == RT_MAT_ISOTROPIC) {
+        /* Isotropic::scatter constant_medium.rs:37-50 */
+        RtV3 attenuation = rt_texture(sc, m.tex, h.u, h.v, h.p);
+        RtV3 dir = rt_random_in_unit_sphere(p.rng);
+        p.beta = rt_mul(p.beta, attenuation);
+        p.ray.o = h.p; p.ray.d = dir;
+    } else {
+        /* impl Material for (): scatter -> None, emitted (0,0,0): main.rs:110-112 */
+        p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
+        p.alive = false;
+        return;
+    }
+    p.depth_left -= 1u;
+}
+
+/* ----------------------------------------------------------------- color -- */
+
+/* Color::into_sampled color.rs:14-21 */
+RT_HD RtV3 rt_into_sampled(RtV3 sum, uint32_t samples_per_pixel) {
+    double scale = 1.0 / (double)samples_per_pixel;
+    double r = rt_isnan(sum.x) ? 0.0 : sum.x;
+    double g = rt_isnan(sum.y) ? 0.0 : sum.y;
+    double b = rt_isnan(sum.z) ? 0.0 : sum.z;
+    return rt_v3(r, g, b) * scale;
+}
+/* Display for SampledColor color.rs:56-65: (256 * sqrt(c).clamp(0, 0.999)) as usize */
+RT_HD uint32_t rt_quantize(double c) {
+    double s = rt_sqrt(c);
+    if (s < 0.0) s = 0.0;
+    if (s > 0.999) s = 0.999;
+    double q = 256.0 * s;
+    return (q != q) ? 0u : (uint32_t)q;
+}
+
+/* work item -> (pixel, chunk): items are numbered so that 64 consecutive items
+ * are an 8x8 pixel block of one chunk (rays of one wave start coherent). */
+RT_HD void rt_item_decode(const RtFrame& f, uint64_t item, uint32_t& px, uint32_t& py, uint32_t& chunk) {
+    uint32_t bw = (f.tile_w + 7u) >> 3, bh = (f.tile_h + 7u) >> 3;
+    uint64_t per_chunk = (uint64_t)bw * bh * 64u;
+    chunk = (uint32_t)(item / per_chunk);
+    uint64_t r = item % per_chunk;
+    uint32_t blk = (uint32_t)(r >> 6), in = (uint32_t)(r & 63u);
+    px = (blk % bw) * 8u + (in & 7u);
+    py = (blk / bw) * 8u + (in >> 3);
+}
+RT_HD uint64_t rt_item_count(const RtFrame& f) {
+    uint32_t bw = (f.tile_w + 7u) >> 3, bh = (f.tile_h + 7u) >> 3;
+    return (uint64_t)bw * bh * 64u * f.n_chunks;
+}
+
+#endif

@@ -1,0 +1,122 @@
+/* rt_flat.h -- the flattened (SoA-of-records) scene the device kernel walks.
+ *
+ * The reference keeps the scene as a tree of `Box<dyn Hittable>` /
+ * `Arc<Box<dyn Material>>` / `Box<dyn Texture>` objects (src/hittable.rs:63-72,
+ * src/material.rs:25-50, src/texture.rs:8-10).  The host builds the same graph
+ * (scene_graph.h), then flattens it ONCE into the plain arrays below, which are
+ * uploaded to HBM at context creation and never change.
+ *
+ * Record sizes are multiples of 16 B so one lane fetches a record with
+ * dwordx4 loads.
+ */
+#ifndef RT1W_FLAT_H
+#define RT1W_FLAT_H
+
+#include "rt1w_num.h"
+
+#define RT_NONE 0xFFFFFFFFu
+
+/* node kinds: every `impl Hittable` of the reference */
+enum {
+    RT_BVH2 = 0,      /* BVHChild::Two   src/bvh.rs:11,38-47   d[0..5]=aabb min,max  a=left b=right */
+    RT_BVH1 = 1,      /* BVHChild::One   src/bvh.rs:10,37      d[0..5]=aabb          a=child */
+    RT_SPHERE = 2,    /* src/sphere.rs:16-20      d[0..2]=center d[3]=radius  mat */
+    RT_MSPHERE = 3,   /* src/moving_sphere.rs:13-20 d[0..2]=c0 d[3..5]=c1 d[6]=t0 d[7]=t1 d[8]=radius mat */
+    RT_XY = 4,        /* src/aarect.rs:15-22  d[0..4]=x0,x1,y0,y1,k mat */
+    RT_XZ = 5,        /* src/aarect.rs:25-32  d[0..4]=x0,x1,z0,z1,k mat */
+    RT_YZ = 6,        /* src/aarect.rs:35-42  d[0..4]=y0,y1,z0,z1,k mat */
+    RT_TRANSLATE = 7, /* src/hittable.rs:49-52   d[0..2]=offset   a=child b=parent scope */
+    RT_ROTATE_Y = 8,  /* src/hittable.rs:54-59   d[0]=sin d[1]=cos a=child b=parent scope */
+    RT_FLIP = 9,      /* src/hittable.rs:61      a=child b=parent scope */
+    RT_MEDIUM = 10,   /* src/constant_medium.rs:15-19 d[0]=neg_inv_density mat=phase fn a=boundary root */
+    RT_DEFAULT = 11   /* lights table only: a hittable without pdf_value/random overrides
+                         (src/hittable.rs:66-71 defaults) */
+};
+
+struct RtNode {
+    double d[9];
+    uint32_t kind;
+    uint32_t mat;
+    uint32_t a;
+    uint32_t b;
+    uint32_t pad0, pad1;
+}; /* 96 bytes */
+
+/* material kinds: every `impl Material` */
+enum {
+    RT_MAT_NULL = 0,         /* impl Material for ()      src/material.rs:68 */
+    RT_MAT_LAMBERTIAN = 1,   /* src/material.rs:70-92   tex */
+    RT_MAT_METAL = 2,        /* src/material.rs:98-112  d[0..2]=albedo d[3]=fuzz */
+    RT_MAT_DIELECTRIC = 3,   /* src/material.rs:132-161 d[0]=ir */
+    RT_MAT_DIFFUSE_LIGHT = 4,/* src/material.rs:163-182 tex */
+    RT_MAT_ISOTROPIC = 5     /* src/constant_medium.rs:31-51 tex */
+};
+#define RT_MAT_NEEDS_UV 0x100u /* texture tree of this material reads (u,v): image texture */
+
+struct RtMaterial {
+    double d[4];
+    uint32_t kind; /* low 8 bits kind, RT_MAT_NEEDS_UV flag */
+    uint32_t tex;
+    uint32_t pad0, pad1;
+}; /* 48 bytes */
+
+/* texture kinds: every `impl Texture` used by a scene */
+enum {
+    RT_TEX_SOLID = 0,   /* src/texture.rs:40-44   d=rgb */
+    RT_TEX_CHECKER = 1, /* src/texture.rs:46-55   a=odd b=even */
+    RT_TEX_NOISE = 2,   /* src/texture.rs:57-65   d[0]=scale a=perlin table index */
+    RT_TEX_IMAGE = 3    /* src/texture.rs:67-89   a=width b=height c=byte offset into image pool */
+};
+struct RtTexture {
+    double d[3];
+    uint32_t kind, a, b, c;
+    uint32_t pad0, pad1;
+}; /* 48 bytes */
+
+/* src/perlin.rs:8-13 with POINT_COUNT = 256 */
+struct RtPerlin {
+    double ranvec[256 * 3];
+    uint32_t perm_x[256], perm_y[256], perm_z[256];
+};
+
+/* src/camera.rs:7-18 */
+struct RtCamera {
+    RtV3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+    double lens_radius, time0, time1;
+};
+
+/* what the kernel sees (device pointers on the GPU, host pointers in the CPU
+ * test build of the same core) */
+struct RtSceneView {
+    const RtNode* nodes;
+    const RtNode* lights;
+    const RtMaterial* materials;
+    const RtTexture* textures;
+    const RtPerlin* perlin;
+    const uint8_t* images;
+    uint32_t root;
+    uint32_t n_nodes;
+    uint32_t n_lights;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t pad;
+    RtCamera camera;
+    RtV3 background;
+};
+
+/* one render call (mirrors the loop bounds of src/main.rs:957-992) */
+struct RtFrame {
+    uint32_t width, height;       /* full image, src/main.rs:799,939 */
+    uint32_t x0, y0, tile_w, tile_h; /* tile rendered by this call; y counts reference rows j */
+    uint32_t spp;                 /* samples rendered by this call */
+    uint32_t sample_offset;       /* first absolute sample index (sample-range sharding) */
+    uint32_t max_depth;           /* MAX_DEPTH, src/main.rs:801 */
+    uint32_t global_seed;
+    uint32_t chunk;               /* samples per work item; pixel sum = sum over chunks of chunk sums */
+    uint32_t n_chunks;
+};
+
+#define RT_STACK_CAP 32      /* traversal stack entries per lane (LDS) */
+#define RT_MAX_SCOPE_DEPTH 3 /* nested Translate/RotateY/FlipFace wrappers above a primitive */
+
+#endif

@@ -1,0 +1,634 @@
+/* scene.cpp -- scene half of the C ABI (include/rt1w.h): constructors, BVH build,
+ * camera, flatten.  Reference citations are paths under /root/reference/src. */
+#include "scene.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+namespace rt1w {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+/* surrounding_box aabb.rs:35-52 (f64::min / f64::max) */
+static AABB surrounding_box(const AABB& a, const AABB& b) {
+    AABB r;
+    r.minimum = rt_v3(rt_min(a.minimum.x, b.minimum.x), rt_min(a.minimum.y, b.minimum.y),
+                      rt_min(a.minimum.z, b.minimum.z));
+    r.maximum = rt_v3(rt_max(a.maximum.x, b.maximum.x), rt_max(a.maximum.y, b.maximum.y),
+                      rt_max(a.maximum.z, b.maximum.z));
+    return r;
+}
+
+static RtV3 msphere_center(const HostHittable& h, double time) { /* moving_sphere.rs:23-26 */
+    RtV3 c0 = rt_v3(h.d[0], h.d[1], h.d[2]), c1 = rt_v3(h.d[3], h.d[4], h.d[5]);
+    return c0 + ((time - h.d[6]) / (h.d[7] - h.d[6])) * (c1 - c0);
+}
+
+/* Hittable::bounding_box of every implementor */
+static bool bounding_box(const rt1w_scene& s, int id, double time0, double time1, AABB& out) {
+    const HostHittable& h = s.hittables[id];
+    switch (h.kind) {
+        case RT_SPHERE: { /* sphere.rs:65-70 */
+            RtV3 c = rt_v3(h.d[0], h.d[1], h.d[2]), r = rt_v3(h.d[3], h.d[3], h.d[3]);
+            out.minimum = c - r; out.maximum = c + r; return true;
+        }
+        case RT_MSPHERE: { /* moving_sphere.rs:72-84 */
+            RtV3 r = rt_v3(h.d[8], h.d[8], h.d[8]);
+            AABB b0{msphere_center(h, time0) - r, msphere_center(h, time0) + r};
+            AABB b1{msphere_center(h, time1) - r, msphere_center(h, time1) + r};
+            out = surrounding_box(b0, b1); return true;
+        }
+        case RT_XY: /* aarect.rs:74-79 */
+            out.minimum = rt_v3(h.d[0], h.d[2], h.d[4] - 0.0001);
+            out.maximum = rt_v3(h.d[1], h.d[3], h.d[4] + 0.0001); return true;
+        case RT_XZ: /* aarect.rs:112-117 */
+            out.minimum = rt_v3(h.d[0], h.d[4] - 0.0001, h.d[2]);
+            out.maximum = rt_v3(h.d[1], h.d[4] + 0.0001, h.d[3]); return true;
+        case RT_YZ: /* aarect.rs:180-185 */
+            out.minimum = rt_v3(h.d[4] - 0.0001, h.d[0], h.d[2]);
+            out.maximum = rt_v3(h.d[4] + 0.0001, h.d[1], h.d[3]); return true;
+        case H_AABOX: out = h.box; return true; /* aabox.rs:98-103 */
+        case H_BVH: out = h.box; return true;   /* bvh.rs:21-23 */
+        case RT_TRANSLATE: { /* hittable.rs:228-233 */
+            AABB c;
+            if (!bounding_box(s, h.child, time0, time1, c)) return false;
+            RtV3 off = rt_v3(h.d[0], h.d[1], h.d[2]);
+            out.minimum = c.minimum + off; out.maximum = c.maximum + off; return true;
+        }
+        case RT_ROTATE_Y: /* hittable.rs:281-283 */
+            if (!h.has_box) return false;
+            out = h.box; return true;
+        case RT_FLIP: return bounding_box(s, h.child, time0, time1, out);   /* hittable.rs:294-296 */
+        case RT_MEDIUM: return bounding_box(s, h.child, time0, time1, out); /* constant_medium.rs:54-56 */
+        default: return false;
+    }
+}
+
+/* float-ord 0.3.1 FloatOrd: total order on the bit pattern */
+static uint64_t float_ord_key(double x) {
+    uint64_t u = rt_d2u(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+/* BVHNode::new bvh.rs:54-103.  Returns hittable id of the new node or <0. */
+static int bvh_new(rt1w_scene& s, std::vector<int> objects, double time0, double time1) {
+    size_t len = objects.size();
+    if (len == 0) { set_error("objects mut not be empty (bvh.rs:61)"); return RT1W_ERR_INVALID; }
+    HostHittable node;
+    node.kind = H_BVH;
+    node.has_box = true;
+    if (len == 1) {
+        int obj = objects.back();
+        if (!bounding_box(s, obj, time0, time1, node.box)) {
+            set_error("Bounding Box is required (bvh.rs:67)"); return RT1W_ERR_INVALID;
+        }
+        node.left = obj;
+    } else if (len == 2) {
+        int left = objects[1];  /* objects.pop(): the LAST element becomes left, bvh.rs:72 */
+        int right = objects[0];
+        AABB lb, rb;
+        if (!bounding_box(s, left, time0, time1, lb) || !bounding_box(s, right, time0, time1, rb)) {
+            set_error("Bounding Box is required (bvh.rs:74-75)"); return RT1W_ERR_INVALID;
+        }
+        node.box = surrounding_box(lb, rb);
+        node.left = left; node.right = right;
+    } else {
+        uint32_t axis = rt_gen_below(s.rng, 3u); /* rng.gen_range(0..=2) bvh.rs:84 */
+        std::vector<std::pair<uint64_t, int>> keyed;
+        keyed.reserve(len);
+        for (int o : objects) {
+            AABB b;
+            if (!bounding_box(s, o, time0, time1, b)) {
+                set_error("Bounding Box is required (bvh.rs:86)"); return RT1W_ERR_INVALID;
+            }
+            keyed.push_back({float_ord_key(rt_get(b.minimum, (int)axis)), o});
+        }
+        /* sort_by_key is a stable sort */
+        std::stable_sort(keyed.begin(), keyed.end(),
+                         [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) {
+                             return a.first < b.first;
+                         });
+        std::vector<int> left, right;
+        for (size_t i = 0; i < len; ++i) (i < len / 2 ? left : right).push_back(keyed[i].second);
+        int l = bvh_new(s, left, time0, time1);
+        if (l < 0) return l;
+        int r = bvh_new(s, right, time0, time1);
+        if (r < 0) return r;
+        node.box = surrounding_box(s.hittables[l].box, s.hittables[r].box);
+        node.left = l; node.right = r;
+        s.hittables[l].used = s.hittables[r].used = true;
+    }
+    s.hittables.push_back(node);
+    return (int)s.hittables.size() - 1;
+}
+
+/* ---- flatten ---------------------------------------------------------- */
+
+struct Flattener {
+    rt1w_scene& s;
+    std::vector<RtNode>& out;
+    uint32_t max_scope = 0;
+    bool media = false;
+    bool ok = true;
+    int err = RT1W_OK;
+
+    static RtNode blank(uint32_t kind) {
+        RtNode n;
+        std::memset(&n, 0, sizeof n);
+        n.kind = kind; n.mat = 0; n.a = RT_NONE; n.b = RT_NONE;
+        return n;
+    }
+    void fail(int code, const char* msg) { if (ok) { ok = false; err = code; set_error(msg); } }
+
+    /* returns node index; *need = stack entries in use beyond the popped entry of
+     * this node while its subtree is processed */
+    uint32_t emit(int id, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary, uint32_t* need) {
+        const HostHittable h = s.hittables[id];
+        *need = 0;
+        if (!ok) return RT_NONE;
+        switch (h.kind) {
+            case RT_SPHERE: case RT_MSPHERE: case RT_XY: case RT_XZ: case RT_YZ: {
+                RtNode n = blank(h.kind);
+                std::memcpy(n.d, h.d, sizeof n.d);
+                n.mat = (uint32_t)h.mat;
+                out.push_back(n);
+                return (uint32_t)out.size() - 1;
+            }
+            case H_AABOX: /* AABox::hit delegates to the side BVH, aabox.rs:88-96 */
+                return emit(h.child, parent_scope, scope_depth, in_boundary, need);
+            case H_BVH: {
+                uint32_t idx = (uint32_t)out.size();
+                RtNode n = blank(h.right >= 0 ? RT_BVH2 : RT_BVH1);
+                n.d[0] = h.box.minimum.x; n.d[1] = h.box.minimum.y; n.d[2] = h.box.minimum.z;
+                n.d[3] = h.box.maximum.x; n.d[4] = h.box.maximum.y; n.d[5] = h.box.maximum.z;
+                out.push_back(n);
+                uint32_t na = 0, nb = 0;
+                uint32_t a = emit(h.left, parent_scope, scope_depth, in_boundary, &na);
+                uint32_t b = RT_NONE;
+                if (h.right >= 0) b = emit(h.right, parent_scope, scope_depth, in_boundary, &nb);
+                out[idx].a = a; out[idx].b = b;
+                *need = (h.right >= 0) ? std::max(2u, std::max(1u + na, nb)) : std::max(1u, na);
+                return idx;
+            }
+            case RT_TRANSLATE: case RT_ROTATE_Y: case RT_FLIP: {
+                if (scope_depth + 1 > RT_MAX_SCOPE_DEPTH) {
+                    fail(RT1W_ERR_UNSUPPORTED, "more than RT_MAX_SCOPE_DEPTH nested Translate/RotateY/FlipFace wrappers");
+                    return RT_NONE;
+                }
+                max_scope = std::max(max_scope, scope_depth + 1);
+                uint32_t idx = (uint32_t)out.size();
+                RtNode n = blank(h.kind);
+                std::memcpy(n.d, h.d, sizeof n.d);
+                n.b = parent_scope;
+                out.push_back(n);
+                uint32_t nc = 0;
+                uint32_t c = emit(h.child, idx, scope_depth + 1, in_boundary, &nc);
+                out[idx].a = c;
+                *need = std::max(2u, 1u + nc);
+                return idx;
+            }
+            case RT_MEDIUM: {
+                if (in_boundary) {
+                    fail(RT1W_ERR_UNSUPPORTED, "ConstantMedium inside a ConstantMedium boundary");
+                    return RT_NONE;
+                }
+                media = true;
+                uint32_t idx = (uint32_t)out.size();
+                RtNode n = blank(RT_MEDIUM);
+                n.d[0] = h.d[0];
+                n.mat = (uint32_t)h.mat;
+                out.push_back(n);
+                uint32_t nc = 0;
+                /* the boundary is traversed with the medium's own ray as its outer ray */
+                uint32_t c = emit(h.child, RT_NONE, 0, true, &nc);
+                out[idx].a = c;
+                *need = 1u + nc;
+                return idx;
+            }
+            default:
+                fail(RT1W_ERR_INVALID, "unknown hittable kind");
+                return RT_NONE;
+        }
+    }
+};
+
+static bool texture_needs_uv(const rt1w_scene& s, uint32_t tex) {
+    const RtTexture& t = s.textures[tex];
+    if (t.kind == RT_TEX_IMAGE) return true;
+    if (t.kind == RT_TEX_CHECKER) return texture_needs_uv(s, t.a) || texture_needs_uv(s, t.b);
+    return false;
+}
+
+} // namespace rt1w
+
+using namespace rt1w;
+
+/* ---- helpers for the ABI ---------------------------------------------- */
+
+#define CHECK_SCENE(s)                                                       \
+    if (!(s)) { set_error("null scene"); return RT1W_ERR_INVALID; }           \
+    if ((s)->committed) { set_error("scene is committed (immutable)"); return RT1W_ERR_STATE; }
+
+static bool valid_tex(const rt1w_scene* s, int t) { return t >= 0 && (size_t)t < s->textures.size(); }
+static bool valid_mat(const rt1w_scene* s, int m) { return m >= 0 && (size_t)m < s->materials.size(); }
+static int take_child(rt1w_scene* s, int id) {
+    if (id < 0 || (size_t)id >= s->hittables.size()) { set_error("bad hittable id"); return RT1W_ERR_INVALID; }
+    if (s->hittables[id].used) { set_error("hittable id already owned by a parent"); return RT1W_ERR_INVALID; }
+    s->hittables[id].used = true;
+    return RT1W_OK;
+}
+static int add_hittable(rt1w_scene* s, const HostHittable& h) {
+    s->hittables.push_back(h);
+    return (int)s->hittables.size() - 1;
+}
+static int add_material(rt1w_scene* s, uint32_t kind, uint32_t tex, double d0, double d1, double d2, double d3) {
+    RtMaterial m;
+    std::memset(&m, 0, sizeof m);
+    m.kind = kind; m.tex = tex; m.d[0] = d0; m.d[1] = d1; m.d[2] = d2; m.d[3] = d3;
+    s->materials.push_back(m);
+    return (int)s->materials.size() - 1;
+}
+
+extern "C" {
+
+const char* rt1w_last_error(void) { return g_error.c_str(); }
+const char* rt1w_version(void) { return "rt1w-mi355x 0.1 (gfx950, f64, philox4x32-10)"; }
+
+int rt1w_scene_create(uint64_t build_seed, rt1w_scene** out) {
+    if (!out) { set_error("null out"); return RT1W_ERR_INVALID; }
+    rt1w_scene* s = new (std::nothrow) rt1w_scene();
+    if (!s) { set_error("out of memory"); return RT1W_ERR_NOMEM; }
+    s->rng = rt_rng_build(build_seed);
+    *out = s;
+    return RT1W_OK;
+}
+void rt1w_scene_destroy(rt1w_scene* s) { delete s; }
+
+int rt1w_scene_rng_f64(rt1w_scene* s, double* out) {
+    CHECK_SCENE(s);
+    if (!out) { set_error("null out"); return RT1W_ERR_INVALID; }
+    *out = rt_gen_f64(s->rng);
+    return RT1W_OK;
+}
+int rt1w_scene_rng_range(rt1w_scene* s, double low, double high, double* out) {
+    CHECK_SCENE(s);
+    if (!out || !(low < high)) { set_error("bad range"); return RT1W_ERR_INVALID; }
+    *out = rt_gen_range(s->rng, low, high);
+    return RT1W_OK;
+}
+
+/* ---- textures ---- */
+int rt1w_texture_solid(rt1w_scene* s, const double rgb[3]) {
+    CHECK_SCENE(s);
+    if (!rgb) { set_error("null rgb"); return RT1W_ERR_INVALID; }
+    RtTexture t; std::memset(&t, 0, sizeof t);
+    t.kind = RT_TEX_SOLID; t.d[0] = rgb[0]; t.d[1] = rgb[1]; t.d[2] = rgb[2];
+    s->textures.push_back(t);
+    return (int)s->textures.size() - 1;
+}
+int rt1w_texture_checker(rt1w_scene* s, int odd, int even) {
+    CHECK_SCENE(s);
+    if (!valid_tex(s, odd) || !valid_tex(s, even)) { set_error("bad texture id"); return RT1W_ERR_INVALID; }
+    RtTexture t; std::memset(&t, 0, sizeof t);
+    t.kind = RT_TEX_CHECKER; t.a = (uint32_t)odd; t.b = (uint32_t)even;
+    s->textures.push_back(t);
+    return (int)s->textures.size() - 1;
+}
+int rt1w_texture_noise_tables(rt1w_scene* s, double scale, const double ranvec[768],
+                              const uint32_t perm_x[256], const uint32_t perm_y[256],
+                              const uint32_t perm_z[256]) {
+    CHECK_SCENE(s);
+    if (!ranvec || !perm_x || !perm_y || !perm_z) { set_error("null table"); return RT1W_ERR_INVALID; }
+    for (int i = 0; i < 256; ++i)
+        if (perm_x[i] > 255u || perm_y[i] > 255u || perm_z[i] > 255u) {
+            set_error("perm entry out of range"); return RT1W_ERR_INVALID;
+        }
+    RtPerlin p;
+    std::memcpy(p.ranvec, ranvec, sizeof p.ranvec);
+    std::memcpy(p.perm_x, perm_x, sizeof p.perm_x);
+    std::memcpy(p.perm_y, perm_y, sizeof p.perm_y);
+    std::memcpy(p.perm_z, perm_z, sizeof p.perm_z);
+    s->perlin.push_back(p);
+    RtTexture t; std::memset(&t, 0, sizeof t);
+    t.kind = RT_TEX_NOISE; t.d[0] = scale; t.a = (uint32_t)s->perlin.size() - 1;
+    s->textures.push_back(t);
+    return (int)s->textures.size() - 1;
+}
+int rt1w_texture_noise(rt1w_scene* s, double scale) {
+    CHECK_SCENE(s);
+    /* Perlin::new perlin.rs:25-43 */
+    RtPerlin p;
+    for (int i = 0; i < 256; ++i) {
+        double x = rt_gen_range(s->rng, -1.0, 1.0);
+        double y = rt_gen_range(s->rng, -1.0, 1.0);
+        double z = rt_gen_range(s->rng, -1.0, 1.0);
+        RtV3 v = rt_normalize(rt_v3(x, y, z));
+        p.ranvec[i * 3 + 0] = v.x; p.ranvec[i * 3 + 1] = v.y; p.ranvec[i * 3 + 2] = v.z;
+    }
+    uint32_t* perms[3] = {p.perm_x, p.perm_y, p.perm_z};
+    for (int a = 0; a < 3; ++a) { /* generate_perm perlin.rs:16-23; shuffle = Fisher-Yates from the end */
+        uint32_t* q = perms[a];
+        for (uint32_t i = 0; i < 256; ++i) q[i] = i;
+        for (uint32_t i = 255; i >= 1; --i) {
+            uint32_t j = rt_gen_below(s->rng, i + 1u);
+            std::swap(q[i], q[j]);
+        }
+    }
+    return rt1w_texture_noise_tables(s, scale, p.ranvec, p.perm_x, p.perm_y, p.perm_z);
+}
+int rt1w_texture_image(rt1w_scene* s, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    CHECK_SCENE(s);
+    if (!rgb8 || width == 0 || height == 0) { set_error("bad image"); return RT1W_ERR_INVALID; }
+    size_t bytes = (size_t)width * height * 3;
+    if (s->images.size() + bytes > 0xFFFFFFF0ull) { set_error("image pool too large"); return RT1W_ERR_UNSUPPORTED; }
+    RtTexture t; std::memset(&t, 0, sizeof t);
+    t.kind = RT_TEX_IMAGE; t.a = width; t.b = height; t.c = (uint32_t)s->images.size();
+    s->images.insert(s->images.end(), rgb8, rgb8 + bytes);
+    while (s->images.size() % 16) s->images.push_back(0);
+    s->textures.push_back(t);
+    return (int)s->textures.size() - 1;
+}
+
+/* ---- materials ---- */
+int rt1w_material_lambertian(rt1w_scene* s, int tex) {
+    CHECK_SCENE(s);
+    if (!valid_tex(s, tex)) { set_error("bad texture id"); return RT1W_ERR_INVALID; }
+    return add_material(s, RT_MAT_LAMBERTIAN, (uint32_t)tex, 0, 0, 0, 0);
+}
+int rt1w_material_metal(rt1w_scene* s, const double albedo[3], double fuzz) {
+    CHECK_SCENE(s);
+    if (!albedo) { set_error("null albedo"); return RT1W_ERR_INVALID; }
+    return add_material(s, RT_MAT_METAL, 0, albedo[0], albedo[1], albedo[2], fuzz);
+}
+int rt1w_material_dielectric(rt1w_scene* s, double ir) {
+    CHECK_SCENE(s);
+    return add_material(s, RT_MAT_DIELECTRIC, 0, ir, 0, 0, 0);
+}
+int rt1w_material_diffuse_light(rt1w_scene* s, int tex) {
+    CHECK_SCENE(s);
+    if (!valid_tex(s, tex)) { set_error("bad texture id"); return RT1W_ERR_INVALID; }
+    return add_material(s, RT_MAT_DIFFUSE_LIGHT, (uint32_t)tex, 0, 0, 0, 0);
+}
+int rt1w_material_null(rt1w_scene* s) {
+    CHECK_SCENE(s);
+    return add_material(s, RT_MAT_NULL, 0, 0, 0, 0, 0);
+}
+
+/* ---- hittables ---- */
+int rt1w_hittable_sphere(rt1w_scene* s, const double c[3], double radius, int material) {
+    CHECK_SCENE(s);
+    if (!c || !valid_mat(s, material)) { set_error("bad sphere argument"); return RT1W_ERR_INVALID; }
+    HostHittable h; h.kind = RT_SPHERE; h.mat = material;
+    h.d[0] = c[0]; h.d[1] = c[1]; h.d[2] = c[2]; h.d[3] = radius;
+    return add_hittable(s, h);
+}
+int rt1w_hittable_moving_sphere(rt1w_scene* s, const double c0[3], const double c1[3], double time0,
+                                double time1, double radius, int material) {
+    CHECK_SCENE(s);
+    if (!c0 || !c1 || !valid_mat(s, material)) { set_error("bad moving_sphere argument"); return RT1W_ERR_INVALID; }
+    HostHittable h; h.kind = RT_MSPHERE; h.mat = material;
+    h.d[0] = c0[0]; h.d[1] = c0[1]; h.d[2] = c0[2]; h.d[3] = c1[0]; h.d[4] = c1[1]; h.d[5] = c1[2];
+    h.d[6] = time0; h.d[7] = time1; h.d[8] = radius;
+    return add_hittable(s, h);
+}
+static int add_rect(rt1w_scene* s, uint32_t kind, double a0, double a1, double b0, double b1, double k, int material) {
+    CHECK_SCENE(s);
+    if (!valid_mat(s, material)) { set_error("bad material id"); return RT1W_ERR_INVALID; }
+    HostHittable h; h.kind = kind; h.mat = material;
+    h.d[0] = a0; h.d[1] = a1; h.d[2] = b0; h.d[3] = b1; h.d[4] = k;
+    return add_hittable(s, h);
+}
+int rt1w_hittable_xy_rect(rt1w_scene* s, double x0, double x1, double y0, double y1, double k, int m) {
+    return add_rect(s, RT_XY, x0, x1, y0, y1, k, m);
+}
+int rt1w_hittable_xz_rect(rt1w_scene* s, double x0, double x1, double z0, double z1, double k, int m) {
+    return add_rect(s, RT_XZ, x0, x1, z0, z1, k, m);
+}
+int rt1w_hittable_yz_rect(rt1w_scene* s, double y0, double y1, double z0, double z1, double k, int m) {
+    return add_rect(s, RT_YZ, y0, y1, z0, z1, k, m);
+}
+int rt1w_hittable_aabox(rt1w_scene* s, const double p0[3], const double p1[3], int material) {
+    CHECK_SCENE(s);
+    if (!p0 || !p1 || !valid_mat(s, material)) { set_error("bad aabox argument"); return RT1W_ERR_INVALID; }
+    /* AABox::new aabox.rs:22-84: six sides in this order, then BVHNode::new(sides, 0.0, 1.0, rng) */
+    std::vector<int> sides;
+    sides.push_back(rt1w_hittable_xy_rect(s, p0[0], p1[0], p0[1], p1[1], p1[2], material));
+    sides.push_back(rt1w_hittable_xy_rect(s, p0[0], p1[0], p0[1], p1[1], p0[2], material));
+    sides.push_back(rt1w_hittable_xz_rect(s, p0[0], p1[0], p0[2], p1[2], p1[1], material));
+    sides.push_back(rt1w_hittable_xz_rect(s, p0[0], p1[0], p0[2], p1[2], p0[1], material));
+    sides.push_back(rt1w_hittable_yz_rect(s, p0[1], p1[1], p0[2], p1[2], p1[0], material));
+    sides.push_back(rt1w_hittable_yz_rect(s, p0[1], p1[1], p0[2], p1[2], p0[0], material));
+    for (int id : sides) s->hittables[id].used = true;
+    int bvh = bvh_new(*s, sides, 0.0, 1.0);
+    if (bvh < 0) return bvh;
+    s->hittables[bvh].used = true;
+    HostHittable h; h.kind = H_AABOX; h.child = bvh; h.has_box = true;
+    h.box.minimum = rt_v3(p0[0], p0[1], p0[2]); h.box.maximum = rt_v3(p1[0], p1[1], p1[2]);
+    return add_hittable(s, h);
+}
+int rt1w_hittable_translate(rt1w_scene* s, int child, const double offset[3]) {
+    CHECK_SCENE(s);
+    if (!offset) { set_error("null offset"); return RT1W_ERR_INVALID; }
+    int rc = take_child(s, child);
+    if (rc < 0) return rc;
+    HostHittable h; h.kind = RT_TRANSLATE; h.child = child;
+    h.d[0] = offset[0]; h.d[1] = offset[1]; h.d[2] = offset[2];
+    return add_hittable(s, h);
+}
+int rt1w_hittable_rotate_y(rt1w_scene* s, int child, double time0, double time1, double angle_deg) {
+    CHECK_SCENE(s);
+    int rc = take_child(s, child);
+    if (rc < 0) return rc;
+    /* RotateY::new hittable.rs:158-202; Deg -> Rad is deg * (PI/180) in cgmath */
+    double radians = angle_deg * (RT_PI / 180.0);
+    double sin_theta, cos_theta;
+    rt_sincos(radians, sin_theta, cos_theta);
+    HostHittable h; h.kind = RT_ROTATE_Y; h.child = child;
+    h.d[0] = sin_theta; h.d[1] = cos_theta;
+    AABB bbox;
+    if (bounding_box(*s, child, time0, time1, bbox)) {
+        RtV3 mn = rt_v3(RT_INF, RT_INF, RT_INF), mx = rt_v3(-RT_INF, -RT_INF, -RT_INF);
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    double fi = (double)i, fj = (double)j, fk = (double)k;
+                    double x = fi * bbox.maximum.x + (1.0 - fi) * bbox.minimum.x;
+                    double y = fj * bbox.maximum.y + (1.0 - fj) * bbox.minimum.y;
+                    double z = fk * bbox.maximum.z + (1.0 - fk) * bbox.minimum.z;
+                    double newx = cos_theta * x + sin_theta * z;
+                    double newz = -sin_theta * x + cos_theta * z;
+                    mn = rt_v3(rt_min(mn.x, newx), rt_min(mn.y, y), rt_min(mn.z, newz));
+                    mx = rt_v3(rt_max(mx.x, newx), rt_max(mx.y, y), rt_max(mx.z, newz));
+                }
+        h.box.minimum = mn; h.box.maximum = mx; h.has_box = true;
+    }
+    return add_hittable(s, h);
+}
+int rt1w_hittable_flip_face(rt1w_scene* s, int child) {
+    CHECK_SCENE(s);
+    int rc = take_child(s, child);
+    if (rc < 0) return rc;
+    HostHittable h; h.kind = RT_FLIP; h.child = child;
+    return add_hittable(s, h);
+}
+int rt1w_hittable_constant_medium(rt1w_scene* s, int boundary, double density, int texture) {
+    CHECK_SCENE(s);
+    if (!valid_tex(s, texture)) { set_error("bad texture id"); return RT1W_ERR_INVALID; }
+    int rc = take_child(s, boundary);
+    if (rc < 0) return rc;
+    /* ConstantMedium::new constant_medium.rs:22-28 */
+    HostHittable h; h.kind = RT_MEDIUM; h.child = boundary;
+    h.mat = add_material(s, RT_MAT_ISOTROPIC, (uint32_t)texture, 0, 0, 0, 0);
+    h.d[0] = -1.0 / density;
+    return add_hittable(s, h);
+}
+int rt1w_hittable_bvh(rt1w_scene* s, const int* children, uint32_t n, double time0, double time1) {
+    CHECK_SCENE(s);
+    if (n > 0 && !children) { set_error("null children"); return RT1W_ERR_INVALID; }
+    std::vector<int> objs(children, children + n);
+    for (int id : objs) {
+        int rc = take_child(s, id);
+        if (rc < 0) return rc;
+    }
+    return bvh_new(*s, objs, time0, time1);
+}
+
+/* ---- scene-level ---- */
+int rt1w_scene_set_world(rt1w_scene* s, int hittable) {
+    CHECK_SCENE(s);
+    int rc = take_child(s, hittable);
+    if (rc < 0) return rc;
+    s->world = hittable;
+    return RT1W_OK;
+}
+int rt1w_scene_set_lights(rt1w_scene* s, const int* hittables, uint32_t n) {
+    CHECK_SCENE(s);
+    if (n > 0 && !hittables) { set_error("null lights"); return RT1W_ERR_INVALID; }
+    std::vector<int> l(hittables, hittables + n);
+    for (int id : l) {
+        int rc = take_child(s, id);
+        if (rc < 0) return rc;
+    }
+    s->lights = l;
+    return RT1W_OK;
+}
+int rt1w_scene_set_background(rt1w_scene* s, const double rgb[3]) {
+    CHECK_SCENE(s);
+    if (!rgb) { set_error("null rgb"); return RT1W_ERR_INVALID; }
+    s->background = rt_v3(rgb[0], rgb[1], rgb[2]);
+    return RT1W_OK;
+}
+int rt1w_scene_set_camera(rt1w_scene* s, const double look_from[3], const double look_at[3],
+                          const double vup[3], double vfov_deg, double aspect_ratio, double aperture,
+                          double focus_dist, double time0, double time1) {
+    CHECK_SCENE(s);
+    if (!look_from || !look_at || !vup) { set_error("null camera vector"); return RT1W_ERR_INVALID; }
+    if (!(time0 < time1)) { set_error("camera needs time0 < time1 (gen_range panics otherwise, camera.rs:71)"); return RT1W_ERR_INVALID; }
+    /* Camera::new camera.rs:22-59 */
+    RtV3 lf = rt_v3(look_from[0], look_from[1], look_from[2]);
+    RtV3 la = rt_v3(look_at[0], look_at[1], look_at[2]);
+    RtV3 up = rt_v3(vup[0], vup[1], vup[2]);
+    double theta = vfov_deg * (RT_PI / 180.0);
+    double h = rt_tan(theta / 2.0);
+    double viewport_height = 2.0 * h;
+    double viewport_width = aspect_ratio * viewport_height;
+    RtCamera c;
+    c.w = rt_normalize(lf - la);
+    c.u = rt_normalize(rt_cross(up, c.w));
+    c.v = rt_cross(c.w, c.u);
+    c.origin = lf;
+    c.horizontal = focus_dist * viewport_width * c.u;
+    c.vertical = focus_dist * viewport_height * c.v;
+    c.lower_left_corner = c.origin - c.horizontal / 2.0 - c.vertical / 2.0 - focus_dist * c.w;
+    c.lens_radius = aperture / 2.0;
+    c.time0 = time0; c.time1 = time1;
+    s->camera = c; s->has_camera = true;
+    return RT1W_OK;
+}
+
+int rt1w_scene_commit(rt1w_scene* s) {
+    CHECK_SCENE(s);
+    if (s->world < 0) { set_error("world not set"); return RT1W_ERR_STATE; }
+    if (!s->has_camera) { set_error("camera not set"); return RT1W_ERR_STATE; }
+    /* material flags */
+    for (RtMaterial& m : s->materials) {
+        uint32_t k = m.kind & 0xFFu;
+        bool has_tex = (k == RT_MAT_LAMBERTIAN || k == RT_MAT_DIFFUSE_LIGHT || k == RT_MAT_ISOTROPIC);
+        m.kind = k | ((has_tex && texture_needs_uv(*s, m.tex)) ? RT_MAT_NEEDS_UV : 0u);
+    }
+    s->flat_nodes.clear();
+    Flattener f{*s, s->flat_nodes};
+    uint32_t need = 0;
+    uint32_t root = f.emit(s->world, RT_NONE, 0, false, &need);
+    if (!f.ok) { s->flat_nodes.clear(); return f.err; }
+    s->flat_root = root;
+    s->stack_need = 1u + need;
+    s->scope_depth = f.max_scope;
+    s->has_media = f.media;
+    if (s->stack_need > RT_STACK_CAP) {
+        set_error("scene needs a deeper traversal stack than RT_STACK_CAP");
+        s->flat_nodes.clear();
+        return RT1W_ERR_UNSUPPORTED;
+    }
+    /* lights: only XZRect and Sphere override pdf_value/random (aarect.rs:119-147,
+     * sphere.rs:72-99); everything else keeps the trait defaults (hittable.rs:66-71) */
+    s->flat_lights.clear();
+    for (int id : s->lights) {
+        const HostHittable& h = s->hittables[id];
+        RtNode n = Flattener::blank(RT_DEFAULT);
+        if (h.kind == RT_XZ || h.kind == RT_SPHERE) {
+            n.kind = h.kind;
+            std::memcpy(n.d, h.d, sizeof n.d);
+            n.mat = (uint32_t)h.mat;
+        }
+        s->flat_lights.push_back(n);
+    }
+    s->committed = true;
+    return RT1W_OK;
+}
+
+int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
+    if (!s || !out) { set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
+    out->n_nodes = (uint32_t)s->flat_nodes.size();
+    out->n_lights = (uint32_t)s->flat_lights.size();
+    out->n_materials = (uint32_t)s->materials.size();
+    out->n_textures = (uint32_t)s->textures.size();
+    out->n_perlin = (uint32_t)s->perlin.size();
+    out->stack_need = s->stack_need;
+    out->scope_depth = s->scope_depth;
+    out->has_media = s->has_media ? 1u : 0u;
+    out->bytes = s->flat_nodes.size() * sizeof(RtNode) + s->flat_lights.size() * sizeof(RtNode) +
+                 s->materials.size() * sizeof(RtMaterial) + s->textures.size() * sizeof(RtTexture) +
+                 s->perlin.size() * sizeof(RtPerlin) + s->images.size();
+    return RT1W_OK;
+}
+
+int64_t rt1w_scene_copy_flat(const rt1w_scene* s, int what, void* buf, uint64_t cap) {
+    if (!s) { set_error("null scene"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
+    const void* src = nullptr;
+    uint64_t bytes = 0;
+    struct CamBg { RtCamera cam; RtV3 bg; uint32_t root, pad; } cb;
+    switch (what) {
+        case 0: src = s->flat_nodes.data(); bytes = s->flat_nodes.size() * sizeof(RtNode); break;
+        case 1: src = s->flat_lights.data(); bytes = s->flat_lights.size() * sizeof(RtNode); break;
+        case 2: src = s->materials.data(); bytes = s->materials.size() * sizeof(RtMaterial); break;
+        case 3: src = s->textures.data(); bytes = s->textures.size() * sizeof(RtTexture); break;
+        case 4: src = s->perlin.data(); bytes = s->perlin.size() * sizeof(RtPerlin); break;
+        case 5: src = s->images.data(); bytes = s->images.size(); break;
+        case 6:
+            std::memset(&cb, 0, sizeof cb);
+            cb.cam = s->camera; cb.bg = s->background; cb.root = s->flat_root;
+            src = &cb; bytes = sizeof cb; break;
+        default: set_error("bad selector"); return RT1W_ERR_INVALID;
+    }
+    if (!buf) return (int64_t)bytes;
+    if (cap < bytes) { set_error("buffer too small"); return RT1W_ERR_INVALID; }
+    if (bytes) std::memcpy(buf, src, bytes);
+    return (int64_t)bytes;
+}
+
+} /* extern "C" */

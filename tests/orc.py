@@ -1,0 +1,116 @@
+"""Loader for the CPU oracles (oracle/*.so).  Test infrastructure only."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_P = C.c_void_p
+
+
+def _build():
+    need = [os.path.join(ORACLE_DIR, n) for n in ("liborc_rt1w.so", "liborc_flat.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+_build()
+A = C.CDLL(os.path.join(ORACLE_DIR, "liborc_rt1w.so"))
+B = C.CDLL(os.path.join(ORACLE_DIR, "liborc_flat.so"))
+
+A.orc_scene_build.restype = _P
+A.orc_scene_build.argtypes = [C.c_int, C.c_uint64, C.c_double, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
+A.orc_scene_free.argtypes = [_P]
+A.orc_render.restype = C.c_int
+A.orc_render.argtypes = [_P] + [C.c_uint32] * 10 + [C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]
+A.orc_reflectance.restype = C.c_double
+A.orc_reflectance.argtypes = [C.c_double, C.c_double]
+A.orc_light_pdf_value.restype = C.c_double
+A.orc_light_pdf_value.argtypes = [C.c_int, _P, _P, _P]
+A.orc_prim_hit.argtypes = [C.c_int, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P]
+A.orc_aabb_hit.argtypes = [_P, _P, _P, _P, C.c_double, C.c_double]
+A.orc_num_eval.argtypes = [C.c_int, _P, _P, _P, C.c_uint64]
+A.orc_stream.argtypes = [C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_uint32, _P, C.c_uint32]
+A.orc_camera_ray.argtypes = [_P, C.c_double, C.c_double, C.c_uint64, C.c_uint32, _P]
+A.orc_refract.argtypes = [_P, _P, C.c_double, _P]
+
+
+def rt():
+    return importlib.import_module("raytracing-1w_amd")
+
+
+def default_aspect(arm):
+    return 1.0 if (arm in (5, 6) or arm < 0 or arm > 6) else 16.0 / 9.0
+
+
+class OracleScene:
+    """Literal recursive oracle (oracle/oracle.cpp)."""
+
+    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None):
+        if aspect_ratio is None:
+            aspect_ratio = default_aspect(arm)
+        self.earth = None
+        ew = eh = 0
+        ptr = None
+        if arm == 3 or arm < 0 or arm > 6:
+            self.earth = np.ascontiguousarray(earth if earth is not None else rt().earth_rgb8())
+            eh, ew = self.earth.shape[:2]
+            ptr = self.earth.ctypes.data_as(_P)
+        d = (C.c_uint32 * 3)()
+        self._h = A.orc_scene_build(arm, build_seed, aspect_ratio, ptr, ew, eh, C.byref(d))
+        if not self._h:
+            raise RuntimeError("oracle scene build failed")
+        self.defaults = (d[0], d[1], d[2])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            A.orc_scene_free(self._h)
+            self._h = None
+
+    def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, out_sum=False, threads=None):
+        x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
+        out = np.empty((th, tw, 3), dtype=np.float64)
+        seg = C.c_uint64()
+        threads = threads or min(16, os.cpu_count() or 1)
+        rc = A.orc_render(self._h, width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed,
+                          1 if out_sum else 0, threads, out.ctypes.data_as(_P), C.byref(seg))
+        assert rc == 0
+        return out, {"segments": seg.value, "paths": tw * th * spp}
+
+
+class Frame(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
+                                          "max_depth", "global_seed", "chunk", "n_chunks")]
+
+
+B.orcflat_render.restype = C.c_int
+B.orcflat_render.argtypes = [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.POINTER(Frame),
+                             C.c_int, C.c_int, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+B.orcflat_sizeof.restype = C.c_uint32
+B.orcflat_item_count.restype = C.c_uint64
+B.orcflat_item_count.argtypes = [C.POINTER(Frame)]
+B.orcflat_item_decode.argtypes = [C.POINTER(Frame), C.c_uint64, _P]
+
+
+def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
+                threads=None):
+    """CPU build of the kernel core over the flat arrays of a committed rt1w scene."""
+    x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
+    if chunk == 0:
+        chunk = rt().default_chunk(tw, th, spp)
+    arrs = [scene.flat(i) for i in range(7)]
+    info = scene.info()
+    f = Frame(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, 0)
+    out = np.empty((th, tw, 3), dtype=np.float64)
+    seg = C.c_uint64()
+    mx = C.c_uint32()
+    threads = threads or min(16, os.cpu_count() or 1)
+    ptr = [a.ctypes.data_as(_P) for a in arrs]
+    rc = B.orcflat_render(ptr[0], info["n_nodes"], ptr[1], info["n_lights"], ptr[2], info["n_materials"], ptr[3],
+                          info["n_textures"], ptr[4], ptr[5], ptr[6], C.byref(f), 1 if out_sum else 0, threads,
+                          out.ctypes.data_as(_P), C.byref(seg), C.byref(mx))
+    assert rc == 0, "flat core reported a traversal stack overflow"
+    return out, {"segments": seg.value, "paths": tw * th * spp, "max_stack": mx.value}
