@@ -1,0 +1,62 @@
+"""Generates the committed golden fixtures.  Run in the build container only:
+    python tests/golden/make_golden.py
+(1) block means of the reference's own artefact rest_of_your_life.png (read from
+    /root/reference -- the only output of the reference's own run that exists);
+(2) golden framebuffers of the literal CPU oracle (oracle/oracle.cpp) for small
+    configurations of every scene arm, incl. BASELINE config C1 (Cornell 200x200x64).
+The reference (Rust) cannot be run here, so (2) are oracle outputs, not reference
+outputs; (1) is the reference's.
+"""
+import hashlib, json, os, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import orc
+
+def png_blocks():
+    from PIL import Image
+    im = np.asarray(Image.open('/root/reference/rest_of_your_life.png').convert('RGB'), dtype=np.float64)
+    assert im.shape == (600, 600, 3)
+    b = im.reshape(6, 100, 6, 100, 3).mean(axis=(1, 3))  # [block_row(top first)][block_col][rgb]
+    return {"source": "rest_of_your_life.png (hatoo/raytracing-1w master, README.md:19)", "shape": [600, 600],
+            "block": 100, "channel_means": im.mean(axis=(0, 1)).tolist(), "block_means_top_down": b.tolist()}
+
+CASES = {  # name: (arm, W, H, spp, depth)
+    "c1_cornell_200x200x64": (5, 200, 200, 64, 50),
+    "random_scene_96x64x8": (0, 96, 64, 8, 50),
+    "two_spheres_64x36x8": (1, 64, 36, 8, 50),
+    "two_perlin_64x36x8": (2, 64, 36, 8, 50),
+    "earth_64x36x8": (3, 64, 36, 8, 50),
+    "simple_light_64x36x16": (4, 64, 36, 16, 50),
+    "cornel_smoke_64x64x16": (6, 64, 64, 16, 50),
+    "final_scene_64x64x16": (7, 64, 64, 16, 50),
+    "cornell_depth3_48x48x8": (5, 48, 48, 8, 3),
+}
+
+def main():
+    with open(os.path.join(HERE, 'cornell_png_blocks.json'), 'w') as f:
+        json.dump(png_blocks(), f, indent=1)
+    meta = {}
+    arrays = {}
+    for name, (arm, W, H, spp, depth) in CASES.items():
+        sc = orc.OracleScene(arm, build_seed=1)
+        img, st = sc.render(W, H, spp, max_depth=depth)
+        if img.size > 96 * 64 * 3:   # keep the repo small: centre crop + block means + hash of the full buffer
+            y0, x0 = H // 2 - 16, W // 2 - 16
+            arrays[name + "__crop"] = img[y0:y0 + 32, x0:x0 + 32].copy()
+            bm = img.reshape(H // 20, 20, W // 20, 20, 3).mean(axis=(1, 3))
+            arrays[name + "__block20"] = bm
+            meta[name] = {"arm": arm, "W": W, "H": H, "spp": spp, "depth": depth, "crop": [x0, y0, 32, 32]}
+        else:
+            arrays[name] = img
+            meta[name] = {"arm": arm, "W": W, "H": H, "spp": spp, "depth": depth}
+        meta[name]["sha256_f64"] = hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest()
+        meta[name]["segments"] = st["segments"]
+        meta[name]["mean"] = float(np.nanmean(img))
+        print(name, meta[name]["segments"], meta[name]["mean"])
+    np.savez_compressed(os.path.join(HERE, 'oracle_frames.npz'), **arrays)
+    with open(os.path.join(HERE, 'oracle_frames.json'), 'w') as f:
+        json.dump({"build_seed": 1, "global_seed": 0, "cases": meta}, f, indent=1)
+
+if __name__ == '__main__':
+    main()

@@ -3,6 +3,7 @@ import ctypes as C
 import importlib
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -39,6 +40,8 @@ A.orc_refract.argtypes = [_P, _P, C.c_double, _P]
 
 
 def rt():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     return importlib.import_module("raytracing-1w_amd")
 
 

@@ -1,0 +1,130 @@
+"""The C-ABI library: loads, exports every symbol include/rt1w.h declares, and the host-side
+error behaviour (the reference's panics become error codes).  No compute here (no GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = orc.ROOT
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "rt1w.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt1w_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(rt):
+    lib = C.CDLL(rt.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/rt1w.h but not exported"
+
+
+def test_every_declared_entry_cites_the_reference():
+    src = open(os.path.join(ROOT, "include", "rt1w.h")).read()
+    for fn in ("rt1w_hittable_sphere", "rt1w_hittable_bvh", "rt1w_render", "rt1w_scene_set_camera", "rt1w_quantize"):
+        line = [l for l in src.splitlines() if fn + "(" in l][0]
+        block = src[src.index(line) - 600: src.index(line) + 400]
+        assert re.search(r"\.rs:\d+", block), f"no reference citation near {fn}"
+
+
+def test_struct_layouts_match_between_python_and_c(rt):
+    assert C.sizeof(rt.RenderParams) == 48 and C.sizeof(rt.Stats) == 48
+    assert orc.B.orcflat_sizeof(0) == 96 and orc.B.orcflat_sizeof(1) == 48 and orc.B.orcflat_sizeof(2) == 48
+    assert orc.B.orcflat_sizeof(3) == 9216 and orc.B.orcflat_sizeof(5) == C.sizeof(orc.Frame)
+
+
+def test_error_behaviour(rt):
+    s = rt.Scene(build_seed=1)
+    with pytest.raises(rt.Rt1wError) as e:            # BVHNode::new panics on empty (bvh.rs:61)
+        s.bvh_node([])
+    assert e.value.code == rt.ERR_INVALID and "empty" in str(e.value)
+    with pytest.raises(rt.Rt1wError):
+        s.lambertian(99)                             # bad texture id
+    with pytest.raises(rt.Rt1wError):
+        s.sphere((0, 0, 0), 1.0, 5)                  # bad material id
+    m = s.lambertian(s.solid_color((0.5, 0.5, 0.5)))
+    a = s.sphere((0, 0, 0), 1.0, m)
+    t = s.translate(a, (1, 0, 0))
+    with pytest.raises(rt.Rt1wError):                # Box ownership: a child is owned once
+        s.flip_face(a)
+    with pytest.raises(rt.Rt1wError) as e:
+        s.commit()                                   # no world / camera yet
+    assert e.value.code == rt.ERR_STATE
+    w = s.bvh_node([t])
+    s.set_world(w)
+    s.set_lights([])
+    s.set_background((0, 0, 0))
+    with pytest.raises(rt.Rt1wError):                # gen_range(time0..time1) needs a non-empty range (camera.rs:71)
+        s.set_camera((0, 0, -5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 1.0, 1.0)
+    s.set_camera((0, 0, -5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 0.0, 1.0)
+    s.commit()
+    with pytest.raises(rt.Rt1wError) as e:           # immutable after commit
+        s.solid_color((1, 1, 1))
+    assert e.value.code == rt.ERR_STATE
+    info = s.info()
+    assert info["n_nodes"] == 3 and info["scope_depth"] == 1 and info["n_lights"] == 0
+
+
+def test_unsupported_graph_shapes_are_reported(rt):
+    s = rt.Scene(build_seed=1)
+    m = s.lambertian(s.solid_color((0.5, 0.5, 0.5)))
+    h = s.sphere((0, 0, 0), 1.0, m)
+    for _ in range(4):                               # 4 nested wrappers > RT_MAX_SCOPE_DEPTH
+        h = s.flip_face(h)
+    s.set_world(s.bvh_node([h]))
+    s.set_camera((0, 0, -5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 0.0, 1.0)
+    with pytest.raises(rt.Rt1wError) as e:
+        s.commit()
+    assert e.value.code == rt.ERR_UNSUPPORTED
+
+
+def test_no_cpu_render_path(rt):
+    """Without a GPU the product refuses to render instead of falling back."""
+    if rt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    sc = rt.Scene.reference(5)
+    with pytest.raises(rt.Rt1wError) as e:
+        rt.Context(sc, 0)
+    assert e.value.code == rt.ERR_DEVICE and "no CPU render path" in str(e.value)
+
+
+def test_flattened_cornell_structure(rt):
+    """Sizes derived from the source: 13 primitives, 14 BVH nodes, 3 wrappers; 2 lights."""
+    sc = rt.Scene.reference(5, build_seed=1)
+    info = sc.info()
+    nodes = sc.flat(0).view(np.uint32).reshape(-1, 24)
+    kinds = nodes[:, 18]
+    assert info["n_nodes"] == 30 and info["n_lights"] == 2 and info["has_media"] == 0
+    assert (kinds <= 1).sum() == 14                  # BVH nodes: 7 top + 7 in the box
+    assert ((kinds >= 2) & (kinds <= 6)).sum() == 13 # 5 walls + light + 6 box sides + sphere
+    assert sorted(kinds[kinds >= 7]) == [7, 8, 9]    # Translate, RotateY, FlipFace
+    assert sc.defaults == (600, 600, 100)            # main.rs:868-870
+    # camera block: origin = look_from
+    cam = sc.flat(6).view(np.float64)
+    assert tuple(cam[0:3]) == (278.0, 278.0, -800.0)
+
+
+def test_reference_defaults_table(rt):
+    # main.rs:798-800,817,856,870,898,918-919,939
+    assert rt.Scene.reference(0).defaults == (400, 225, 500)
+    assert rt.Scene.reference(1).defaults == (400, 225, 100)
+    assert rt.Scene.reference(4).defaults == (400, 225, 400)
+    assert rt.Scene.reference(6).defaults == (600, 600, 200)
+    assert rt.Scene.reference(7).defaults == (800, 800, 10000)
+    assert rt.Scene.reference(5, aspect_ratio=16.0 / 9.0).defaults[1] == 337
+
+
+def test_format_ppm_matches_reference_layout(rt):
+    img = np.zeros((2, 3, 3))
+    img[1, 0] = (1.0, 0.25, 0.0)                     # j = 1 is the TOP row (main.rs:957-960)
+    txt = rt.format_ppm(img)
+    lines = txt.split("\n")
+    assert lines[:3] == ["P3", "3 2", "255"]
+    assert lines[3] == "255 128 0" and lines[4] == "0 0 0" and len(lines) == 3 + 6 + 1 and lines[-1] == ""
