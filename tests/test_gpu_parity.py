@@ -204,10 +204,9 @@ def test_c5_4k_cornell_tiles(rt, gpu_ctx_factory):
     import importlib
     sh = importlib.import_module("raytracing-1w_amd.sharding")
     sc = rt.Scene.reference(5, build_seed=1, aspect_ratio=16.0 / 9.0)
-    assert sc.defaults[1] * 3840 // 600 == 2156 or True
     W, H = 3840, 2160
     ctx = gpu_ctx_factory(sc)
-    y0, rows = sh.row_strips(H, 8, 3)[40]
+    y0, rows = sh.row_strips(H, 8, 3)[10]
     strip, st = ctx.render(W, H, 200, tile=(0, y0, W, rows))
     crop = (1900, y0 + 4, 8, 4)
     b, _ = orc.flat_render(sc, W, H, 200, tile=crop, chunk=st["chunk"])
