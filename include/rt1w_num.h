@@ -94,14 +94,14 @@ RT_HD RtPhiloxOut rt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32
 struct RtRng {
     uint32_t k0, k1, c1, c2, c3;
     uint32_t blk;  /* next block index to generate */
-    uint32_t idx;  /* next word in buf, 4 = empty */
-    uint32_t b0, b1, b2, b3;
+    uint32_t left; /* unconsumed words of the current block (0..4); the next one is w0 */
+    uint32_t w0, w1, w2, w3; /* shift register: no indexed access, so the state stays in registers */
 };
 
 RT_HD void rt_rng_refill(RtRng& r) {
     RtPhiloxOut o = rt_philox4x32_10(r.blk, r.c1, r.c2, r.c3, r.k0, r.k1);
-    r.b0 = o.w0; r.b1 = o.w1; r.b2 = o.w2; r.b3 = o.w3;
-    r.blk += 1u; r.idx = 0u;
+    r.w0 = o.w0; r.w1 = o.w1; r.w2 = o.w2; r.w3 = o.w3;
+    r.blk += 1u; r.left = 4u;
 }
 
 /* Stream of sample `sample` of the pixel whose reference seed is `pixel_seed`
@@ -110,7 +110,7 @@ RT_HD RtRng rt_rng_pixel_sample(uint64_t pixel_seed, uint32_t sample, uint32_t g
     RtRng r;
     r.k0 = (uint32_t)pixel_seed; r.k1 = (uint32_t)(pixel_seed >> 32);
     r.c1 = sample; r.c2 = global_seed; r.c3 = RT_DOMAIN_RENDER;
-    r.blk = 0u; r.idx = 4u; r.b0 = r.b1 = r.b2 = r.b3 = 0u;
+    r.blk = 0u; r.left = 0u; r.w0 = r.w1 = r.w2 = r.w3 = 0u;
     return r;
 }
 /* Sequential stream used by the one-shot scene build (replaces the reference's
@@ -119,24 +119,24 @@ RT_HD RtRng rt_rng_build(uint64_t build_seed) {
     RtRng r;
     r.k0 = (uint32_t)build_seed; r.k1 = (uint32_t)(build_seed >> 32);
     r.c1 = 0u; r.c2 = 0u; r.c3 = RT_DOMAIN_BUILD;
-    r.blk = 0u; r.idx = 4u; r.b0 = r.b1 = r.b2 = r.b3 = 0u;
+    r.blk = 0u; r.left = 0u; r.w0 = r.w1 = r.w2 = r.w3 = 0u;
     return r;
 }
 
 RT_HD uint32_t rt_next_u32(RtRng& r) {
-    if (r.idx >= 4u) rt_rng_refill(r);
-    uint32_t i = r.idx;
-    uint32_t w = (i == 0u) ? r.b0 : (i == 1u) ? r.b1 : (i == 2u) ? r.b2 : r.b3;
-    r.idx = i + 1u;
+    if (r.left == 0u) rt_rng_refill(r);
+    uint32_t w = r.w0;
+    r.w0 = r.w1; r.w1 = r.w2; r.w2 = r.w3;
+    r.left -= 1u;
     return w;
 }
 RT_HD uint64_t rt_next_u64(RtRng& r) {
-    uint32_t i = (r.idx + 1u) & ~1u;
-    if (i >= 4u) { rt_rng_refill(r); i = 0u; }
-    uint32_t lo = (i == 0u) ? r.b0 : r.b2;
-    uint32_t hi = (i == 0u) ? r.b1 : r.b3;
-    r.idx = i + 2u;
-    return ((uint64_t)hi << 32) | lo;
+    if (r.left & 1u) { r.w0 = r.w1; r.w1 = r.w2; r.w2 = r.w3; r.left -= 1u; } /* even-align */
+    if (r.left == 0u) rt_rng_refill(r);
+    uint64_t v = ((uint64_t)r.w1 << 32) | r.w0;
+    r.w0 = r.w2; r.w1 = r.w3;
+    r.left -= 2u;
+    return v;
 }
 
 /* rand 0.8 `rng.gen::<f64>()`: 53 random bits scaled into [0,1). */
@@ -198,7 +198,8 @@ RT_HD double rt_kcos(double x, double y) {
  * return NaN for |x| >= 2^30, far outside any scene's coordinates, so the
  * double->integer conversion below is always in range on both targets).
  * Returns quadrant (0..3), remainder in (hi, lo). */
-RT_HD int rt_rem_pio2(double x, double& hi, double& lo) {
+struct RtRem { double hi, lo; int n; };
+RT_HD RtRem rt_rem_pio2(double x) {
     const double INVPIO2 = 6.36619772367581382433e-01;
     const double P1 = 1.57079632673412561417e+00;  /* 0x3FF921FB54400000 */
     const double P1T = 6.07710050650619224932e-11;
@@ -225,37 +226,37 @@ RT_HD int rt_rem_pio2(double x, double& hi, double& lo) {
     r = t3 - w3;
     w = fn * P3T - ((t3 - r) - w3);
     y0 = r - w;
-    hi = y0;
-    lo = (r - y0) - w;
-    return n;
+    RtRem o;
+    o.hi = y0;
+    o.lo = (r - y0) - w;
+    o.n = n;
+    return o;
 }
 #define RT_TRIG_MAX 1073741824.0 /* 2^30 */
 RT_HD double rt_sin(double x) {
     if (rt_abs(x) < 0.78539816339744830962) return rt_ksin(x, 0.0);
     if (!(rt_abs(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
-    double hi, lo;
-    int n = rt_rem_pio2(x, hi, lo);
-    if (n == 0) return rt_ksin(hi, lo);
-    if (n == 1) return rt_kcos(hi, lo);
-    if (n == 2) return -rt_ksin(hi, lo);
-    return -rt_kcos(hi, lo);
+    RtRem q = rt_rem_pio2(x);
+    if (q.n == 0) return rt_ksin(q.hi, q.lo);
+    if (q.n == 1) return rt_kcos(q.hi, q.lo);
+    if (q.n == 2) return -rt_ksin(q.hi, q.lo);
+    return -rt_kcos(q.hi, q.lo);
 }
 RT_HD double rt_cos(double x) {
     if (rt_abs(x) < 0.78539816339744830962) return rt_kcos(x, 0.0);
     if (!(rt_abs(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
-    double hi, lo;
-    int n = rt_rem_pio2(x, hi, lo);
-    if (n == 0) return rt_kcos(hi, lo);
-    if (n == 1) return -rt_ksin(hi, lo);
-    if (n == 2) return -rt_kcos(hi, lo);
-    return rt_ksin(hi, lo);
+    RtRem q = rt_rem_pio2(x);
+    if (q.n == 0) return rt_kcos(q.hi, q.lo);
+    if (q.n == 1) return -rt_ksin(q.hi, q.lo);
+    if (q.n == 2) return -rt_kcos(q.hi, q.lo);
+    return rt_ksin(q.hi, q.lo);
 }
 /* sin and cos of one argument with one shared reduction (same values as above) */
 RT_HD void rt_sincos(double x, double& s, double& c) {
     double hi = x, lo = 0.0;
     int n = 0;
     if (!(rt_abs(x) < RT_TRIG_MAX)) { s = c = rt_u2d(0x7FF8000000000000ull); return; }
-    if (!(rt_abs(x) < 0.78539816339744830962)) n = rt_rem_pio2(x, hi, lo);
+    if (!(rt_abs(x) < 0.78539816339744830962)) { RtRem q = rt_rem_pio2(x); hi = q.hi; lo = q.lo; n = q.n; }
     double ks = rt_ksin(hi, lo), kc = rt_kcos(hi, lo);
     s = (n == 0) ? ks : (n == 1) ? kc : (n == 2) ? -ks : -kc;
     c = (n == 0) ? kc : (n == 1) ? -ks : (n == 2) ? -kc : ks;

@@ -137,7 +137,7 @@ RT_HD RtRayOD rt_scope_in(const RtNode& s, RtRayOD r) {
 /* the way back out: hittable.rs:215-225, :255-278, :288-291.  `inner` is the ray in
  * the wrapper's space (`moved` / `rotated_r`): both re-run HitRecord::new with it,
  * taking the child's already-forwarded normal as "outward" (reference quirk Q5). */
-RT_HD void rt_scope_out(const RtNode& s, const RtRayOD& inner, RtHit& h) {
+RT_HD void rt_scope_out(const RtNode& s, RtRayOD inner, RtHit& h) {
     if (s.kind == RT_TRANSLATE) {
         h.p = h.p + rt_v3(s.d[0], s.d[1], s.d[2]);
         bool front = rt_dot(inner.d, h.n) < 0.0;
@@ -190,7 +190,7 @@ RT_HD void rt_sphere_uv(RtV3 p, double& u, double& v) {
  * 96-109,164-177, constant_medium.rs:98-106) in the leaf's space.  u,v are only
  * evaluated when the material's texture reads them (image texture); they are
  * unobservable otherwise. */
-RT_HD void rt_leaf_record(const RtNode& nd, const RtRayOD& r, double time, double t, bool want_uv,
+RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bool want_uv,
                           RtHit& h) {
     h.t = t; h.u = 0.0; h.v = 0.0; h.mat = nd.mat;
     h.p = rt_at(r.o, r.d, t);
