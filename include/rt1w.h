@@ -121,6 +121,9 @@ typedef struct rt1w_scene_info {
     uint32_t stack_need;   /* traversal stack entries the scene needs */
     uint32_t scope_depth;  /* deepest wrapper nesting */
     uint32_t has_media;
+    uint32_t has_textures; /* any non-solid texture */
+    uint32_t has_moving;   /* any MovingSphere */
+    uint32_t variant;      /* kernel variant rt1w_render picks (V0..V3) */
     uint64_t bytes;        /* bytes uploaded per context */
 } rt1w_scene_info;
 int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out);
@@ -136,6 +139,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out);
 void rt1w_context_destroy(rt1w_context* c);
 
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
+#define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
 typedef struct rt1w_render_params {
     uint32_t width, height;         /* image_width, image_height (src/main.rs:799,939) */
@@ -155,6 +159,7 @@ typedef struct rt1w_stats {
     double total_ms;       /* host wall time of the call incl. device->host copy */
     uint32_t chunk, n_chunks;
     uint32_t grid, block;
+    uint32_t variant, reserved;
 } rt1w_stats;
 
 /* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */

@@ -33,6 +33,18 @@ struct HostStack {
 };
 }
 
+template <class Cfg>
+static void run_path(const RtSceneView& sc, const RtFrame& f, uint32_t px, uint32_t py, uint32_t s, HostStack& stk,
+                     RtV3& sum, uint64_t& segs) {
+    RtPath path;
+    rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+    while (path.alive) {
+        segs += path.depth_left != 0u ? 1u : 0u;
+        rt_path_step<Cfg>(sc, path, stk);
+    }
+    sum = sum + path.radiance;
+}
+
 extern "C" {
 
 struct orcflat_cam_bg { RtCamera cam; RtV3 bg; uint32_t root, pad; };
@@ -40,8 +52,8 @@ struct orcflat_cam_bg { RtCamera cam; RtV3 bg; uint32_t root, pad; };
 /* arrays are the bytes of rt1w_scene_copy_flat selectors 0..6 */
 int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint32_t n_lights, const void* materials,
                    uint32_t n_materials, const void* textures, uint32_t n_textures, const void* perlin, const void* images,
-                   const void* cam_bg, const RtFrame* frame, int out_sum, int threads, double* out, uint64_t* segments_out,
-                   uint32_t* max_stack_out) {
+                   const void* cam_bg, const RtFrame* frame, int variant, int out_sum, int threads, double* out,
+                   uint64_t* segments_out, uint32_t* max_stack_out) {
     RtSceneView sc;
     std::memset(&sc, 0, sizeof sc);
     const orcflat_cam_bg* cb = (const orcflat_cam_bg*)cam_bg;
@@ -70,13 +82,12 @@ int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint
                 uint32_t s_end = s + f.chunk < f.spp ? s + f.chunk : f.spp;
                 RtV3 sum = rt_v3(0.0, 0.0, 0.0);
                 for (; s < s_end; ++s) {
-                    RtPath path;
-                    rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
-                    while (path.alive) {
-                        segs += path.depth_left != 0u ? 1u : 0u;
-                        rt_path_step(sc, path, stk);
+                    switch (variant) { /* the same feature-specialised variants the GPU library builds */
+                        case 0: run_path<RtCfgV0>(sc, f, px, py, s, stk, sum, segs); break;
+                        case 1: run_path<RtCfgV1>(sc, f, px, py, s, stk, sum, segs); break;
+                        case 2: run_path<RtCfgV2>(sc, f, px, py, s, stk, sum, segs); break;
+                        default: run_path<RtCfgV3>(sc, f, px, py, s, stk, sum, segs); break;
                     }
-                    sum = sum + path.radiance;
                 }
                 total = total + sum;
             }

@@ -49,13 +49,14 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("chunk", C.c_uint32), ("n_chunks", C.c_uint32),
-                ("grid", C.c_uint32), ("block", C.c_uint32)]
+                ("grid", C.c_uint32), ("block", C.c_uint32), ("variant", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_lights", C.c_uint32), ("n_materials", C.c_uint32),
                 ("n_textures", C.c_uint32), ("n_perlin", C.c_uint32), ("stack_need", C.c_uint32),
-                ("scope_depth", C.c_uint32), ("has_media", C.c_uint32), ("bytes", C.c_uint64)]
+                ("scope_depth", C.c_uint32), ("has_media", C.c_uint32), ("has_textures", C.c_uint32),
+                ("has_moving", C.c_uint32), ("variant", C.c_uint32), ("bytes", C.c_uint64)]
 
 
 _P = C.c_void_p
@@ -292,22 +293,24 @@ class Context:
     __del__ = close
 
     @staticmethod
-    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum):
+    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk,
-                            OUT_SUM if out_sum else 0)
+        flags = (OUT_SUM if out_sum else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags)
 
-    def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False):
+    def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
+               variant=None):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict)."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant)
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
         st = Stats()
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
-    def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False):
+    def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0,
+                      out_sum=False, variant=None):
         """Same, into device memory `d_ptr` (int address, e.g. torch tensor .data_ptr())."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant)
         st = Stats()
         _ck(_lib.rt1w_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.byref(st)))
         return {n: getattr(st, n) for n, _ in Stats._fields_}

@@ -45,9 +45,11 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 }
 
 /* counters[0] = next work item, counters[1] = traced segments */
+template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                             unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    /* the sweep variants need no traversal stack (and no LDS at all) */
+    __shared__ uint32_t stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
     LdsStack stk;
     stk.base = stack_mem + threadIdx.x;
     stk.sp = 0;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RtSceneView sc, RtF
             rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
         }
         segs += path.depth_left != 0u ? 1ull : 0ull;
-        rt_path_step(sc, path, stk);
+        rt_path_step<Cfg>(sc, path, stk);
         if (!path.alive) {
             sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
             ++s;
@@ -158,8 +160,15 @@ struct rt1w_context {
     double* d_partial = nullptr; size_t partial_bytes = 0;
     double* d_out = nullptr; size_t out_bytes = 0;
     unsigned long long* d_counters = nullptr;
-    int grid = 0;
+    int grid[RT_N_VARIANTS] = {0, 0, 0, 0};
+    int variant = 0;
+    bool has_media = false, has_tex = false, has_msphere = false;
+    uint32_t n_nodes = 0;
 };
+
+typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
+static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV0>, rt_render_kernel<RtCfgV1>,
+                                                         rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>};
 
 namespace {
 
@@ -199,11 +208,19 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
         if (!hip_ok(hipMalloc((void**)&c->d_partial, need), "hipMalloc(partial sums)")) return RT1W_ERR_NOMEM;
         c->partial_bytes = need;
     }
-    unsigned long long init[2] = {(unsigned long long)c->grid * RT_BLOCK, 0ull};
+    int variant = c->variant;
+    if (p->flags >> 8) {
+        variant = (int)((p->flags >> 8) & 0xFFu) - 1;
+        if (!rt_variant_valid(variant, c->n_nodes, c->has_media, c->has_tex, c->has_msphere)) {
+            rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
+        }
+    }
+    const int grid = c->grid[variant];
+    unsigned long long init[2] = {(unsigned long long)grid * RT_BLOCK, 0ull};
     if (!hip_ok(hipMemcpyAsync(c->d_counters, init, sizeof init, hipMemcpyHostToDevice, c->stream), "counter init")) return RT1W_ERR_DEVICE;
     if (!hip_ok(hipStreamSynchronize(c->stream), "counter init sync")) return RT1W_ERR_DEVICE;
     (void)hipEventRecord(c->ev0, c->stream);
-    hipLaunchKernelGGL(rt_render_kernel, dim3(c->grid), dim3(RT_BLOCK), 0, c->stream, c->view, f, c->d_partial, c->d_counters);
+    hipLaunchKernelGGL(g_kernels[variant], dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->view, f, c->d_partial, c->d_counters);
     {
         unsigned int rb = 256;
         unsigned int rg = (unsigned int)((npix + rb - 1) / rb);
@@ -222,7 +239,8 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
         stats->segments = cnt[1];
         stats->kernel_ms = ms;
         stats->chunk = f.chunk; stats->n_chunks = f.n_chunks;
-        stats->grid = (uint32_t)c->grid; stats->block = RT_BLOCK;
+        stats->grid = (uint32_t)grid; stats->block = RT_BLOCK;
+        stats->variant = (uint32_t)variant; stats->reserved = 0;
     }
     return RT1W_OK;
 }
@@ -282,13 +300,18 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     v.camera = s->camera; v.background = s->background;
     /* persistent grid: as many blocks as are resident at once */
     hipDeviceProp_t prop;
-    int per_cu = 0;
-    if (!hip_ok(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties") ||
-        !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel, RT_BLOCK, 0), "occupancy query")) {
-        rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties")) { rt1w_context_destroy(c); return RT1W_ERR_DEVICE; }
+    for (int v = 0; v < RT_N_VARIANTS; ++v) {
+        int per_cu = 0;
+        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels[v], RT_BLOCK, 0), "occupancy query")) {
+            rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+        }
+        if (per_cu < 1) per_cu = 1;
+        c->grid[v] = prop.multiProcessorCount * per_cu;
     }
-    if (per_cu < 1) per_cu = 1;
-    c->grid = prop.multiProcessorCount * per_cu;
+    c->has_media = s->has_media; c->has_tex = s->has_tex; c->has_msphere = s->has_msphere;
+    c->n_nodes = (uint32_t)s->flat_nodes.size();
+    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere);
     *out = c;
     return RT1W_OK;
 }

@@ -28,6 +28,14 @@
 
 #define RT_POP_FLAG 0x80000000u
 
+/* "does any lane of this wave want this?" -- a scalar branch on the GPU; the CPU test
+ * build runs one lane at a time */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WAVE_ANY(p) (__ballot((p)) != 0ull)
+#else
+#define RT_WAVE_ANY(p) (p)
+#endif
+
 struct RtRay { RtV3 o, d; double time; };
 struct RtRayOD { RtV3 o, d; };
 
@@ -106,18 +114,24 @@ RT_HD bool rt_rect_t(const RtNode& nd, double oa, double da, double ob, double d
     t_out = t;
     return true;
 }
-RT_HD bool rt_prim_t(const RtNode& nd, RtV3 o, RtV3 d, double time, double t_min, double t_max,
+/* the three rect kinds as one code path: axis selection by value instead of a 3-way branch
+ * (same operands reach the same operations as in rt_rect_t) */
+RT_HD bool rt_rect_any_t(const RtNode& nd, uint32_t kind, RtV3 o, RtV3 d, double t_min, double t_max, double& t) {
+    double oa = kind == RT_XY ? o.z : (kind == RT_XZ ? o.y : o.x);
+    double da = kind == RT_XY ? d.z : (kind == RT_XZ ? d.y : d.x);
+    double ob = kind == RT_YZ ? o.y : o.x;
+    double db = kind == RT_YZ ? d.y : d.x;
+    double oc = kind == RT_XY ? o.y : o.z;
+    double dc = kind == RT_XY ? d.y : d.z;
+    return rt_rect_t(nd, oa, da, ob, db, oc, dc, t_min, t_max, t);
+}
+template <class Cfg>
+RT_HD bool rt_prim_t(const RtNode& nd, uint32_t kind, RtV3 o, RtV3 d, double time, double t_min, double t_max,
                      double& t) {
-    switch (nd.kind) {
-        case RT_SPHERE:
-            return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t);
-        case RT_MSPHERE:
-            return rt_sphere_root(rt_msphere_center(nd, time), nd.d[8], o, d, t_min, t_max, t);
-        case RT_XY: return rt_rect_t(nd, o.z, d.z, o.x, d.x, o.y, d.y, t_min, t_max, t);
-        case RT_XZ: return rt_rect_t(nd, o.y, d.y, o.x, d.x, o.z, d.z, t_min, t_max, t);
-        case RT_YZ: return rt_rect_t(nd, o.x, d.x, o.y, d.y, o.z, d.z, t_min, t_max, t);
-        default: return false;
-    }
+    if (kind >= RT_XY) return rt_rect_any_t(nd, kind, o, d, t_min, t_max, t);
+    if (Cfg::msphere && kind == RT_MSPHERE)
+        return rt_sphere_root(rt_msphere_center(nd, time), nd.d[8], o, d, t_min, t_max, t);
+    return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t);
 }
 
 /* Translate::hit hittable.rs:207-211 / RotateY::hit hittable.rs:238-251: ray into the wrapper's space */
@@ -190,16 +204,17 @@ RT_HD void rt_sphere_uv(RtV3 p, double& u, double& v) {
  * 96-109,164-177, constant_medium.rs:98-106) in the leaf's space.  u,v are only
  * evaluated when the material's texture reads them (image texture); they are
  * unobservable otherwise. */
+template <class Cfg>
 RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bool want_uv,
                           RtHit& h) {
     h.t = t; h.u = 0.0; h.v = 0.0; h.mat = nd.mat;
     h.p = rt_at(r.o, r.d, t);
     RtV3 on;
     if (nd.kind == RT_SPHERE || nd.kind == RT_MSPHERE) {
-        if (nd.kind == RT_SPHERE) on = (h.p - rt_v3(nd.d[0], nd.d[1], nd.d[2])) / nd.d[3];
+        if (!Cfg::msphere || nd.kind == RT_SPHERE) on = (h.p - rt_v3(nd.d[0], nd.d[1], nd.d[2])) / nd.d[3];
         else on = (h.p - rt_msphere_center(nd, time)) / nd.d[8];
-        if (want_uv) rt_sphere_uv(on, h.u, h.v);
-    } else if (nd.kind == RT_MEDIUM) {
+        if (Cfg::tex && want_uv) rt_sphere_uv(on, h.u, h.v);
+    } else if (Cfg::media && nd.kind == RT_MEDIUM) {
         h.n = rt_v3(1.0, 0.0, 0.0);
         h.front = true;
         return;
@@ -208,7 +223,7 @@ RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bo
         if (nd.kind == RT_XY) { on = rt_v3(0.0, 0.0, 1.0); b = r.o.x + t * r.d.x; c = r.o.y + t * r.d.y; }
         else if (nd.kind == RT_XZ) { on = rt_v3(0.0, 1.0, 0.0); b = r.o.x + t * r.d.x; c = r.o.z + t * r.d.z; }
         else { on = rt_v3(1.0, 0.0, 0.0); b = r.o.y + t * r.d.y; c = r.o.z + t * r.d.z; }
-        if (want_uv) {
+        if (Cfg::tex && want_uv) {
             h.u = (b - nd.d[0]) / (nd.d[1] - nd.d[0]);
             h.v = (c - nd.d[2]) / (nd.d[3] - nd.d[2]);
         }
@@ -221,14 +236,15 @@ RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bo
 
 /* Full hit record of the winning leaf: leaf record in its own space, then the
  * wrapper fix-ups innermost to outermost. */
+template <class Cfg>
 RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t prim, uint32_t scope,
                          double t, RtHit& h) {
     const RtNode* nodes = sc.nodes;
-    RtNode nd = nodes[prim];
-    bool want_uv = (sc.materials[nd.mat].kind & RT_MAT_NEEDS_UV) != 0u;
+    const RtNode& nd = nodes[prim];
+    bool want_uv = Cfg::tex && (sc.materials[nd.mat].kind & RT_MAT_NEEDS_UV) != 0u;
     RtRayOD r0; r0.o = world.o; r0.d = world.d;
     if (scope == RT_NONE) {
-        rt_leaf_record(nd, r0, world.time, t, want_uv, h);
+        rt_leaf_record<Cfg>(nd, r0, world.time, t, want_uv, h);
         return;
     }
     RtChain c = rt_chain(nodes, scope);
@@ -236,7 +252,7 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
     RtRayOD r2 = r1, r3 = r1;
     if (c.s1 != RT_NONE) { r2 = rt_scope_in(nodes[c.s1], r1); r3 = r2; }
     if (c.s2 != RT_NONE) r3 = rt_scope_in(nodes[c.s2], r2);
-    rt_leaf_record(nd, r3, world.time, t, want_uv, h);
+    rt_leaf_record<Cfg>(nd, r3, world.time, t, want_uv, h);
     if (c.s2 != RT_NONE) rt_scope_out(nodes[c.s2], r3, h);
     if (c.s1 != RT_NONE) rt_scope_out(nodes[c.s1], r2, h);
     rt_scope_out(nodes[c.s0], r1, h);
@@ -246,13 +262,29 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
 
 RT_HD RtV3 rt_inv3(RtV3 d) { return rt_v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
 
+/* ConstantMedium::hit constant_medium.rs:58-113, given the two boundary roots t1, t2 */
+RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_min, double t_max, RtRng& rng,
+                       double& t_out) {
+    double rec1 = rt_max(t1, t_min);
+    double rec2 = rt_min(t2, t_max);
+    if (rec1 >= rec2) return false;
+    rec1 = rt_max(rec1, 0.0);
+    double ray_length = rt_mag(d);
+    double distance_inside_boundary = (rec2 - rec1) * ray_length;
+    double hit_distance = nd.d[0] * rt_log(rt_gen_f64(rng));
+    if (hit_distance > distance_inside_boundary) return false;
+    t_out = rec1 + hit_distance / ray_length;
+    return true;
+}
+
 /* Closest hit of the subtree `root` for `world` (a ray in the subtree's outer
- * space) within [t_min, t_max].  MEDIA=false is the flavour used for a
- * ConstantMedium's boundary, where only t is consumed (constant_medium.rs:62-69). */
-template <bool MEDIA, class Stack>
-RT_HD bool rt_traverse(const RtSceneView& sc, uint32_t root, const RtRay& world, double t_min,
-                       double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
-                       uint32_t& out_scope) {
+ * space) within [t_min, t_max], with an explicit per-lane stack (LDS on the GPU).
+ * MEDIA=false is the flavour used for a ConstantMedium's boundary, where only t is
+ * consumed (constant_medium.rs:62-69). */
+template <class Cfg, bool MEDIA, class Stack>
+RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& world, double t_min,
+                             double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
+                             uint32_t& out_scope) {
     const RtNode* nodes = sc.nodes;
     RtRayOD w; w.o = world.o; w.d = world.d;
     RtRayOD cur = w;
@@ -281,7 +313,7 @@ RT_HD bool rt_traverse(const RtSceneView& sc, uint32_t root, const RtRay& world,
             }
         } else if (kind <= RT_YZ) {
             double t;
-            if (rt_prim_t(nd, cur.o, cur.d, world.time, t_min, best_t, t)) {
+            if (rt_prim_t<Cfg>(nd, kind, cur.o, cur.d, world.time, t_min, best_t, t)) {
                 best_t = t; best_prim = e; best_scope = scope;
             }
         } else if (kind <= RT_FLIP) {
@@ -292,26 +324,94 @@ RT_HD bool rt_traverse(const RtSceneView& sc, uint32_t root, const RtRay& world,
                 if (kind == RT_ROTATE_Y) inv = rt_inv3(cur.d);
             }
             stk.push(nd.a);
-        } else if (MEDIA && kind == RT_MEDIUM) {
-            /* ConstantMedium::hit constant_medium.rs:58-113 */
+        } else if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
             RtRay br; br.o = cur.o; br.d = cur.d; br.time = world.time;
-            double t1, t2; uint32_t p_, s_;
-            if (!rt_traverse<false>(sc, nd.a, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_)) continue;
-            if (!rt_traverse<false>(sc, nd.a, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_)) continue;
-            double rec1 = rt_max(t1, t_min);
-            double rec2 = rt_min(t2, best_t);
-            if (rec1 >= rec2) continue;
-            rec1 = rt_max(rec1, 0.0);
-            double ray_length = rt_mag(cur.d);
-            double distance_inside_boundary = (rec2 - rec1) * ray_length;
-            double hit_distance = nd.d[0] * rt_log(rt_gen_f64(rng));
-            if (hit_distance > distance_inside_boundary) continue;
-            best_t = rec1 + hit_distance / ray_length;
-            best_prim = e; best_scope = scope;
+            double t1, t2, t; uint32_t p_, s_;
+            if (!rt_traverse_stack<Cfg, false>(sc, nd.a, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_)) continue;
+            if (!rt_traverse_stack<Cfg, false>(sc, nd.a, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_)) continue;
+            if (rt_medium_t(nd, cur.d, t1, t2, t_min, best_t, rng, t)) {
+                best_t = t; best_prim = e; best_scope = scope;
+            }
         }
     }
     out_t = best_t; out_prim = best_prim; out_scope = best_scope;
     return best_prim != RT_NONE;
+}
+
+/* The same traversal without a stack, for small scenes.  Nodes are stored in
+ * depth-first pre-order and every node knows where its subtree ends (`skip`), so
+ * the reference's walk (left subtree, then right subtree) is "visit node n, then
+ * either n+1 or skip[n]": each lane keeps only the index `cur` of the next node it
+ * has to visit.  The loop index n is the same in all lanes of a wave, so the node
+ * record comes in through SCALAR loads, the node kind is a scalar branch (no
+ * divergence between node kinds), and lanes that do not visit node n just sit out
+ * that step.  Every lane still visits exactly the nodes the stack walk would, in
+ * the same order, with the same arithmetic. */
+template <class Cfg, bool MEDIA>
+RT_HD bool rt_traverse_sweep(const RtSceneView& sc, uint32_t root, const RtRay& world, double t_min,
+                             double t_max, RtRng& rng, double& out_t, uint32_t& out_prim, uint32_t& out_scope) {
+    const RtNode* nodes = sc.nodes;
+    RtRayOD w; w.o = world.o; w.d = world.d;
+    RtRayOD cur_ray = w;
+    RtV3 inv = rt_inv3(cur_ray.d);
+    uint32_t scope = RT_NONE, scope_end = RT_NONE;
+    double best_t = t_max;
+    uint32_t best_prim = RT_NONE, best_scope = RT_NONE;
+    const uint32_t end = nodes[root].skip;
+    uint32_t cur = root;
+    for (uint32_t n = root; n < end; ++n) {
+        /* lanes whose wrapper's subtree ended before n go back to the parent's ray */
+        if (RT_WAVE_ANY(scope_end <= n)) {
+            while (scope_end <= n) {
+                scope = nodes[scope].b;
+                scope_end = (scope == RT_NONE) ? RT_NONE : nodes[scope].skip;
+                cur_ray = rt_ray_in_scope(nodes, scope, w);
+                inv = rt_inv3(cur_ray.d);
+            }
+        }
+        bool active = (cur == n);
+        if (!RT_WAVE_ANY(active)) continue;
+        const RtNode& nd = nodes[n];
+        const uint32_t kind = nd.kind;
+        if (active) {
+            if (kind <= RT_BVH1) {
+                cur = rt_aabb_hit(nd.d, cur_ray.o, inv, t_min, best_t) ? n + 1u : nd.skip;
+            } else if (kind <= RT_YZ) {
+                double t;
+                if (rt_prim_t<Cfg>(nd, kind, cur_ray.o, cur_ray.d, world.time, t_min, best_t, t)) {
+                    best_t = t; best_prim = n; best_scope = scope;
+                }
+                cur = n + 1u;
+            } else if (kind <= RT_FLIP) {
+                scope = n; scope_end = nd.skip;
+                if (kind != RT_FLIP) {
+                    cur_ray = rt_scope_in(nd, cur_ray);
+                    if (kind == RT_ROTATE_Y) inv = rt_inv3(cur_ray.d);
+                }
+                cur = n + 1u;
+            } else {
+                if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
+                    RtRay br; br.o = cur_ray.o; br.d = cur_ray.d; br.time = world.time;
+                    double t1, t2, t; uint32_t p_, s_;
+                    if (rt_traverse_sweep<Cfg, false>(sc, nd.a, br, -RT_INF, RT_INF, rng, t1, p_, s_) &&
+                        rt_traverse_sweep<Cfg, false>(sc, nd.a, br, t1 + 0.0001, RT_INF, rng, t2, p_, s_) &&
+                        rt_medium_t(nd, cur_ray.d, t1, t2, t_min, best_t, rng, t)) {
+                        best_t = t; best_prim = n; best_scope = scope;
+                    }
+                }
+                cur = nd.skip;
+            }
+        }
+    }
+    out_t = best_t; out_prim = best_prim; out_scope = best_scope;
+    return best_prim != RT_NONE;
+}
+
+template <class Cfg, class Stack>
+RT_HD bool rt_closest_hit(const RtSceneView& sc, const RtRay& ray, double t_min, double t_max, RtRng& rng,
+                          Stack& stk, double& t, uint32_t& prim, uint32_t& scope) {
+    if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, sc.root, ray, t_min, t_max, rng, t, prim, scope);
+    else return rt_traverse_stack<Cfg, true>(sc, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
 }
 
 /* ------------------------------------------------------------ textures -- */
@@ -362,7 +462,12 @@ RT_HD uint32_t rt_as_u32(double x) {
     return (uint32_t)x;
 }
 /* Texture::value texture.rs:40-89 */
+template <class Cfg>
 RT_HD RtV3 rt_texture(const RtSceneView& sc, uint32_t tex, double u, double v, RtV3 p) {
+    if (!Cfg::tex) { /* every texture of the scene is a SolidColor */
+        const RtTexture& t = sc.textures[tex];
+        return rt_v3(t.d[0], t.d[1], t.d[2]);
+    }
     for (;;) {
         const RtTexture& t = sc.textures[tex];
         if (t.kind == RT_TEX_CHECKER) {
@@ -534,7 +639,7 @@ RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, ui
  * beta = beta (.) W / pdf.  Every terminal adds beta (.) value -- including the zero
  * of depth exhaustion (main.rs:59-61) -- so a non-finite beta poisons the sample
  * exactly as it does through the reference's multiplications. */
-template <class Stack>
+template <class Cfg, class Stack>
 RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
     if (p.depth_left == 0u) {
         p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
@@ -542,13 +647,13 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
         return;
     }
     double t; uint32_t prim, scope;
-    if (!rt_traverse<true>(sc, sc.root, p.ray, 0.001, RT_INF, p.rng, stk, t, prim, scope)) {
+    if (!rt_closest_hit<Cfg>(sc, p.ray, 0.001, RT_INF, p.rng, stk, t, prim, scope)) {
         p.radiance = p.radiance + rt_mul(p.beta, sc.background);
         p.alive = false;
         return;
     }
     RtHit h;
-    rt_finish_hit(sc, p.ray, prim, scope, t, h);
+    rt_finish_hit<Cfg>(sc, p.ray, prim, scope, t, h);
     const RtMaterial& m = sc.materials[h.mat];
     uint32_t mk = m.kind & 0xFFu;
 
@@ -558,7 +663,7 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
      * emitting material never scatters, so a path's radiance is beta (.) its
      * terminal value (light, background, or the zero of depth exhaustion). */
     if (mk == RT_MAT_DIFFUSE_LIGHT) {
-        RtV3 emitted = h.front ? rt_texture(sc, m.tex, h.u, h.v, h.p) : rt_v3(0.0, 0.0, 0.0);
+        RtV3 emitted = h.front ? rt_texture<Cfg>(sc, m.tex, h.u, h.v, h.p) : rt_v3(0.0, 0.0, 0.0);
         p.radiance = p.radiance + rt_mul(p.beta, emitted);
         p.alive = false; /* DiffuseLight::scatter -> None, main.rs:110-112 */
         return;
@@ -566,7 +671,7 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
 
     if (mk == RT_MAT_LAMBERTIAN) {
         /* Lambertian::scatter material.rs:71-80 -> ScatterKind::Pdf(CosinePdf) */
-        RtV3 attenuation = rt_texture(sc, m.tex, h.u, h.v, h.p);
+        RtV3 attenuation = rt_texture<Cfg>(sc, m.tex, h.u, h.v, h.p);
         RtOnb uvw = rt_onb_from_w(h.n);
         RtV3 dir;
         double pdf;
@@ -611,9 +716,9 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
             dir = rt_refract(unit_direction, h.n, refraction_ratio);
         p.beta = rt_mul(p.beta, rt_v3(1.0, 1.0, 1.0));
         p.ray.o = h.p; p.ray.d = dir;
-    } else if (mk == RT_MAT_ISOTROPIC) {
+    } else if (Cfg::media && mk == RT_MAT_ISOTROPIC) {
         /* Isotropic::scatter constant_medium.rs:37-50 */
-        RtV3 attenuation = rt_texture(sc, m.tex, h.u, h.v, h.p);
+        RtV3 attenuation = rt_texture<Cfg>(sc, m.tex, h.u, h.v, h.p);
         RtV3 dir = rt_random_in_unit_sphere(p.rng);
         p.beta = rt_mul(p.beta, attenuation);
         p.ray.o = h.p; p.ray.d = dir;

@@ -39,7 +39,8 @@ struct RtNode {
     uint32_t mat;
     uint32_t a;
     uint32_t b;
-    uint32_t pad0, pad1;
+    uint32_t skip; /* nodes are stored in depth-first pre-order: [index, skip) is this node's subtree */
+    uint32_t pad;
 }; /* 96 bytes */
 
 /* material kinds: every `impl Material` */
@@ -117,6 +118,38 @@ struct RtFrame {
 };
 
 #define RT_STACK_CAP 32      /* traversal stack entries per lane (LDS) */
+#define RT_SWEEP_MAX_NODES 64 /* scenes up to this many nodes use the stackless wave-uniform sweep */
+
+/* compile-time feature set of a kernel variant: code for absent features is not
+ * generated, which is what keeps the register budget of the simple scenes low */
+template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_>
+struct RtCfg {
+    static constexpr bool media = MEDIA_;     /* scene contains ConstantMedium nodes */
+    static constexpr bool tex = TEX_;         /* scene has non-solid textures (checker/noise/image) */
+    static constexpr bool msphere = MSPHERE_; /* scene has MovingSphere primitives */
+    static constexpr bool sweep = SWEEP_;     /* stackless pre-order sweep instead of the LDS stack */
+};
+/* the variants that are built (host picks the cheapest one that covers the scene) */
+typedef RtCfg<false, false, false, true> RtCfgV0; /* small scene, solid colours only, no media, no moving spheres (Cornell box) */
+typedef RtCfg<true, true, true, true> RtCfgV1;    /* small scene, every feature */
+typedef RtCfg<false, true, true, false> RtCfgV2;  /* large scene without media (random_scene) */
+typedef RtCfg<true, true, true, false> RtCfgV3;   /* large scene, every feature (final_scene) */
+#define RT_N_VARIANTS 4
+/* cheapest valid variant for a scene; `force` >= 0 overrides when valid */
+inline int rt_pick_variant(uint32_t n_nodes, bool media, bool tex, bool msphere) {
+    if (n_nodes <= RT_SWEEP_MAX_NODES) return (!media && !tex && !msphere) ? 0 : 1;
+    return media ? 3 : 2;
+}
+inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool msphere) {
+    (void)n_nodes;
+    switch (v) {
+        case 0: return !media && !tex && !msphere;
+        case 1: return true;
+        case 2: return !media;
+        case 3: return true;
+        default: return false;
+    }
+}
 #define RT_MAX_SCOPE_DEPTH 3 /* nested Translate/RotateY/FlipFace wrappers above a primitive */
 
 #endif

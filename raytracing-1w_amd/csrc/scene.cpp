@@ -137,7 +137,7 @@ struct Flattener {
     static RtNode blank(uint32_t kind) {
         RtNode n;
         std::memset(&n, 0, sizeof n);
-        n.kind = kind; n.mat = 0; n.a = RT_NONE; n.b = RT_NONE;
+        n.kind = kind; n.mat = 0; n.a = RT_NONE; n.b = RT_NONE; n.skip = RT_NONE; n.pad = 0;
         return n;
     }
     void fail(int code, const char* msg) { if (ok) { ok = false; err = code; set_error(msg); } }
@@ -563,10 +563,32 @@ int rt1w_scene_commit(rt1w_scene* s) {
     uint32_t need = 0;
     uint32_t root = f.emit(s->world, RT_NONE, 0, false, &need);
     if (!f.ok) { s->flat_nodes.clear(); return f.err; }
+    /* pre-order subtree ends (skip) for the sweep traversal */
+    {
+        std::vector<RtNode>& N = s->flat_nodes;
+        struct R { static uint32_t fill(std::vector<RtNode>& N, uint32_t i) {
+            uint32_t end = i + 1;
+            uint32_t k = N[i].kind;
+            if (k == RT_BVH2) { end = fill(N, N[i].a); end = fill(N, N[i].b); }
+            else if (k == RT_BVH1 || k == RT_TRANSLATE || k == RT_ROTATE_Y || k == RT_FLIP || k == RT_MEDIUM) end = fill(N, N[i].a);
+            N[i].skip = end;
+            return end;
+        } };
+        R::fill(N, root);
+        for (uint32_t i = 0; i < N.size(); ++i) {
+            uint32_t k = N[i].kind;
+            if (k == RT_BVH2 && (N[i].a != i + 1 || N[i].b != N[N[i].a].skip)) { set_error("internal: nodes not in pre-order"); return RT1W_ERR_INVALID; }
+            if ((k == RT_BVH1 || (k >= RT_TRANSLATE && k <= RT_MEDIUM)) && N[i].a != i + 1) { set_error("internal: nodes not in pre-order"); return RT1W_ERR_INVALID; }
+        }
+    }
     s->flat_root = root;
     s->stack_need = 1u + need;
     s->scope_depth = f.max_scope;
     s->has_media = f.media;
+    s->has_tex = false;
+    for (const RtTexture& t : s->textures) if (t.kind != RT_TEX_SOLID) s->has_tex = true;
+    s->has_msphere = false;
+    for (const RtNode& n : s->flat_nodes) if (n.kind == RT_MSPHERE) s->has_msphere = true;
     if (s->stack_need > RT_STACK_CAP) {
         set_error("scene needs a deeper traversal stack than RT_STACK_CAP");
         s->flat_nodes.clear();
@@ -600,6 +622,9 @@ int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
     out->stack_need = s->stack_need;
     out->scope_depth = s->scope_depth;
     out->has_media = s->has_media ? 1u : 0u;
+    out->has_textures = s->has_tex ? 1u : 0u;
+    out->has_moving = s->has_msphere ? 1u : 0u;
+    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere);
     out->bytes = s->flat_nodes.size() * sizeof(RtNode) + s->flat_lights.size() * sizeof(RtNode) +
                  s->materials.size() * sizeof(RtMaterial) + s->textures.size() * sizeof(RtTexture) +
                  s->perlin.size() * sizeof(RtPerlin) + s->images.size();

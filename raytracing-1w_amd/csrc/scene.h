@@ -54,7 +54,7 @@ struct rt1w_scene {
     std::vector<RtNode> flat_nodes, flat_lights;
     uint32_t flat_root = RT_NONE;
     uint32_t stack_need = 0, scope_depth = 0;
-    bool has_media = false;
+    bool has_media = false, has_tex = false, has_msphere = false;
 };
 
 #endif

@@ -91,7 +91,7 @@ class Frame(C.Structure):
 
 B.orcflat_render.restype = C.c_int
 B.orcflat_render.argtypes = [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.POINTER(Frame),
-                             C.c_int, C.c_int, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+                             C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 B.orcflat_sizeof.restype = C.c_uint32
 B.orcflat_item_count.restype = C.c_uint64
 B.orcflat_item_count.argtypes = [C.POINTER(Frame)]
@@ -99,13 +99,16 @@ B.orcflat_item_decode.argtypes = [C.POINTER(Frame), C.c_uint64, _P]
 
 
 def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-                threads=None):
-    """CPU build of the kernel core over the flat arrays of a committed rt1w scene."""
+                threads=None, variant=None):
+    """CPU build of the kernel core over the flat arrays of a committed rt1w scene.
+    `variant`: kernel variant (0..3, see rt_flat.h); default = the one the library picks."""
     x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
     if chunk == 0:
         chunk = rt().default_chunk(tw, th, spp)
     arrs = [scene.flat(i) for i in range(7)]
     info = scene.info()
+    if variant is None:
+        variant = info["variant"]
     f = Frame(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, 0)
     out = np.empty((th, tw, 3), dtype=np.float64)
     seg = C.c_uint64()
@@ -113,7 +116,7 @@ def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offse
     threads = threads or min(16, os.cpu_count() or 1)
     ptr = [a.ctypes.data_as(_P) for a in arrs]
     rc = B.orcflat_render(ptr[0], info["n_nodes"], ptr[1], info["n_lights"], ptr[2], info["n_materials"], ptr[3],
-                          info["n_textures"], ptr[4], ptr[5], ptr[6], C.byref(f), 1 if out_sum else 0, threads,
+                          info["n_textures"], ptr[4], ptr[5], ptr[6], C.byref(f), variant, 1 if out_sum else 0, threads,
                           out.ctypes.data_as(_P), C.byref(seg), C.byref(mx))
     assert rc == 0, "flat core reported a traversal stack overflow"
     return out, {"segments": seg.value, "paths": tw * th * spp, "max_stack": mx.value}

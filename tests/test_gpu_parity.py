@@ -65,6 +65,21 @@ def test_gpu_bit_exact_vs_core_and_close_to_literal(rt, gpu_ctx_factory, arm):
     assert rt.format_ppm(g) == rt.format_ppm(a)          # integer pixel output bit-identical
 
 
+def test_gpu_kernel_variants_agree(rt, gpu_ctx_factory):
+    """Forced variants on the GPU (sweep vs stack, pruned vs full) == the CPU build, bit for bit."""
+    for arm, variants in ((5, (0, 1, 2, 3)), (6, (1, 3)), (0, (1, 2, 3)), (7, (3,))):
+        W, H, spp = SMALL[arm]
+        sc = rt.Scene.reference(arm, build_seed=1)
+        ctx = gpu_ctx_factory(sc)
+        ref, sref = orc.flat_render(sc, W, H, spp, chunk=8)
+        for v in variants:
+            g, sg = ctx.render(W, H, spp, chunk=8, variant=v)
+            assert sg["variant"] == v and sg["segments"] == sref["segments"], (arm, v)
+            assert np.array_equal(g, ref, equal_nan=True), (arm, v)
+    with pytest.raises(rt.Rt1wError):                    # V0 cannot render a scene with media/textures
+        gpu_ctx_factory(rt.Scene.reference(6)).render(16, 16, 1, variant=0)
+
+
 def test_gpu_matches_committed_golden_frames(rt, gpu_ctx_factory):
     meta = json.load(open(os.path.join(HERE, "golden", "oracle_frames.json")))
     gold = np.load(os.path.join(HERE, "golden", "oracle_frames.npz"))
