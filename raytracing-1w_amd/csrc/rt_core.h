@@ -27,6 +27,9 @@
 #include "rt_flat.h"
 
 #define RT_POP_FLAG 0x80000000u
+#ifndef RT_STAT_VISIT
+#define RT_STAT_VISIT(kind) ((void)0) /* hook for offline visit statistics (tools only) */
+#endif
 
 /* "does any lane of this wave want this?" -- a scalar branch on the GPU; the CPU test
  * build runs one lane at a time */
@@ -374,6 +377,7 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, uint32_t root, const RtRay& 
         const RtNode& nd = nodes[n];
         const uint32_t kind = nd.kind;
         if (active) {
+            RT_STAT_VISIT(kind);
             if (kind <= RT_BVH1) {
                 cur = rt_aabb_hit(nd.d, cur_ray.o, inv, t_min, best_t) ? n + 1u : nd.skip;
             } else if (kind <= RT_YZ) {
