@@ -91,53 +91,86 @@ RT_HD RtPhiloxOut rt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32
 #define RT_DOMAIN_RENDER 0x52454E44u /* "REND" */
 #define RT_DOMAIN_BUILD 0x424C4453u  /* "BLDS" */
 
+/* Buffer: A = words of the current block still unconsumed (a0 is the next word, `left` of
+ * them), B = the following block, generated ahead (`bv` set).  Keeping B lets the device
+ * code generate blocks at a few phase starts where most lanes of a wave take part
+ * (rt_rng_reserve / rt_rng_fill) instead of inside every draw; the word stream and its
+ * consumption order are exactly those of a one-block buffer.  No indexed access anywhere,
+ * so the whole state stays in registers. */
 struct RtRng {
     uint32_t k0, k1, c1, c2, c3;
     uint32_t blk;  /* next block index to generate */
-    uint32_t left; /* unconsumed words of the current block (0..4); the next one is w0 */
-    uint32_t w0, w1, w2, w3; /* shift register: no indexed access, so the state stays in registers */
+    uint32_t left; /* unconsumed words of A (0..4) */
+    uint32_t a0, a1, a2, a3;
+    uint32_t bv;   /* B holds a generated block */
+    uint32_t b0, b1, b2, b3;
 };
 
-RT_HD void rt_rng_refill(RtRng& r) {
-    RtPhiloxOut o = rt_philox4x32_10(r.blk, r.c1, r.c2, r.c3, r.k0, r.k1);
-    r.w0 = o.w0; r.w1 = o.w1; r.w2 = o.w2; r.w3 = o.w3;
-    r.blk += 1u; r.left = 4u;
-}
+#if defined(RT_RNG_CHECK)
+#include <cstdio>
+#include <cstdlib>
+#define RT_RNG_ASSERT(c) do { if (!(c)) { std::fprintf(stderr, "rt1w_num.h: RNG buffer underflow (missing reserve)\n"); std::abort(); } } while (0)
+#else
+#define RT_RNG_ASSERT(c) ((void)0)
+#endif
 
+RT_HD void rt_rng_gen_b(RtRng& r) {
+    RtPhiloxOut o = rt_philox4x32_10(r.blk, r.c1, r.c2, r.c3, r.k0, r.k1);
+    r.b0 = o.w0; r.b1 = o.w1; r.b2 = o.w2; r.b3 = o.w3;
+    r.blk += 1u; r.bv = 1u;
+}
+/* make sure the next n words can be taken without generating (n <= 4 + left) */
+RT_HD void rt_rng_reserve(RtRng& r, uint32_t n) {
+    if (r.left + (r.bv << 2) < n) rt_rng_gen_b(r);
+}
+/* words a 64-bit draw (resp. two of them) may consume, counting the alignment skip */
+RT_HD uint32_t rt_rng_need_u64(const RtRng& r) { return 2u + (r.left & 1u); }
+RT_HD uint32_t rt_rng_need_2u64(const RtRng& r) { return 4u + (r.left & 1u); }
+/* top up B unconditionally */
+RT_HD void rt_rng_fill(RtRng& r) { if (!r.bv) rt_rng_gen_b(r); }
+
+RT_HD RtRng rt_rng_make(uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2, uint32_t c3) {
+    RtRng r;
+    r.k0 = k0; r.k1 = k1; r.c1 = c1; r.c2 = c2; r.c3 = c3;
+    r.blk = 0u; r.left = 0u; r.a0 = r.a1 = r.a2 = r.a3 = 0u;
+    r.bv = 0u; r.b0 = r.b1 = r.b2 = r.b3 = 0u;
+    return r;
+}
 /* Stream of sample `sample` of the pixel whose reference seed is `pixel_seed`
  * (= j*W+i, src/main.rs:964). */
 RT_HD RtRng rt_rng_pixel_sample(uint64_t pixel_seed, uint32_t sample, uint32_t global_seed) {
-    RtRng r;
-    r.k0 = (uint32_t)pixel_seed; r.k1 = (uint32_t)(pixel_seed >> 32);
-    r.c1 = sample; r.c2 = global_seed; r.c3 = RT_DOMAIN_RENDER;
-    r.blk = 0u; r.left = 0u; r.w0 = r.w1 = r.w2 = r.w3 = 0u;
-    return r;
+    return rt_rng_make((uint32_t)pixel_seed, (uint32_t)(pixel_seed >> 32), sample, global_seed, RT_DOMAIN_RENDER);
 }
 /* Sequential stream used by the one-shot scene build (replaces the reference's
  * entropy-seeded `MyRng::from_entropy()`, src/main.rs:803). */
 RT_HD RtRng rt_rng_build(uint64_t build_seed) {
-    RtRng r;
-    r.k0 = (uint32_t)build_seed; r.k1 = (uint32_t)(build_seed >> 32);
-    r.c1 = 0u; r.c2 = 0u; r.c3 = RT_DOMAIN_BUILD;
-    r.blk = 0u; r.left = 0u; r.w0 = r.w1 = r.w2 = r.w3 = 0u;
-    return r;
+    return rt_rng_make((uint32_t)build_seed, (uint32_t)(build_seed >> 32), 0u, 0u, RT_DOMAIN_BUILD);
 }
 
-RT_HD uint32_t rt_next_u32(RtRng& r) {
-    if (r.left == 0u) rt_rng_refill(r);
-    uint32_t w = r.w0;
-    r.w0 = r.w1; r.w1 = r.w2; r.w2 = r.w3;
+/* ---- unchecked takes: the caller has reserved ---- */
+RT_HD void rt_rng_pull(RtRng& r) { /* A is empty: B becomes A */
+    RT_RNG_ASSERT(r.bv);
+    r.a0 = r.b0; r.a1 = r.b1; r.a2 = r.b2; r.a3 = r.b3;
+    r.left = 4u; r.bv = 0u;
+}
+RT_HD uint32_t rt_take_u32(RtRng& r) {
+    if (r.left == 0u) rt_rng_pull(r);
+    uint32_t w = r.a0;
+    r.a0 = r.a1; r.a1 = r.a2; r.a2 = r.a3;
     r.left -= 1u;
     return w;
 }
-RT_HD uint64_t rt_next_u64(RtRng& r) {
-    if (r.left & 1u) { r.w0 = r.w1; r.w1 = r.w2; r.w2 = r.w3; r.left -= 1u; } /* even-align */
-    if (r.left == 0u) rt_rng_refill(r);
-    uint64_t v = ((uint64_t)r.w1 << 32) | r.w0;
-    r.w0 = r.w2; r.w1 = r.w3;
+RT_HD uint64_t rt_take_u64(RtRng& r) {
+    if (r.left & 1u) { r.a0 = r.a1; r.a1 = r.a2; r.a2 = r.a3; r.left -= 1u; } /* even-align */
+    if (r.left == 0u) rt_rng_pull(r);
+    uint64_t v = ((uint64_t)r.a1 << 32) | r.a0;
+    r.a0 = r.a2; r.a1 = r.a3;
     r.left -= 2u;
     return v;
 }
+/* ---- checked draws (reserve + take): what the host code and the literal oracle use ---- */
+RT_HD uint32_t rt_next_u32(RtRng& r) { rt_rng_reserve(r, 1u); return rt_take_u32(r); }
+RT_HD uint64_t rt_next_u64(RtRng& r) { rt_rng_reserve(r, rt_rng_need_u64(r)); return rt_take_u64(r); }
 
 /* rand 0.8 `rng.gen::<f64>()`: 53 random bits scaled into [0,1). */
 RT_HD double rt_gen_f64(RtRng& r) {
@@ -166,6 +199,20 @@ RT_HD uint32_t rt_gen_below(RtRng& r, uint32_t n) {
         if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
     }
 }
+
+/* ---- the same shapes over reserved words (device core; see rt_rng_reserve) ---- */
+RT_HD double rt_take_f64(RtRng& r) { return (double)(rt_take_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
+RT_HD double rt_take_range(RtRng& r, double low, double high) {
+    double scale = high - low;
+    double v12 = rt_u2d((rt_take_u64(r) >> 12) | 0x3FF0000000000000ull);
+    double res = (v12 - 1.0) * scale + low;
+    while (!(res < high)) { /* rounding pushed the value onto `high`: draw again (checked) */
+        v12 = rt_u2d((rt_next_u64(r) >> 12) | 0x3FF0000000000000ull);
+        res = (v12 - 1.0) * scale + low;
+    }
+    return res;
+}
+RT_HD bool rt_take_bool(RtRng& r) { return (int32_t)rt_take_u32(r) < 0; }
 
 /* -------------------------------------------------- elementary functions -- */
 /* All of these are evaluated with + - * / only, in the order written, so the

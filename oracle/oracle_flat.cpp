@@ -40,7 +40,8 @@ static void run_path(const RtSceneView& sc, const RtFrame& f, uint32_t px, uint3
     rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
     while (path.alive) {
         segs += path.depth_left != 0u ? 1u : 0u;
-        rt_path_step<Cfg>(sc, path, stk);
+        RtGlobalNodes ns{sc.nodes};
+        rt_path_step<Cfg>(sc, ns, path, stk);
     }
     sum = sum + path.radiance;
 }

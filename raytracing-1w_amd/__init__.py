@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt1w.so")
+LIB_PATH = os.environ.get("RT1W_LIB") or os.path.join(_HERE, "librt1w.so")  # RT1W_LIB: diagnostic builds only
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -115,6 +115,7 @@ _sig("rt1w_resolve", C.c_int, _P, C.c_uint64, C.c_uint32, _P)
 _sig("rt1w_quantize", C.c_int, _P, C.c_uint64, _P)
 _sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
 _sig("rt1w_debug_eval", C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64)
+_sig("rt1w_debug_stamps", C.c_int, _P, C.POINTER(C.c_uint64 * 16), C.c_int)
 
 
 def last_error():
@@ -314,6 +315,11 @@ class Context:
         st = Stats()
         _ck(_lib.rt1w_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.byref(st)))
         return {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def debug_stamps(self, reset=True):
+        out = (C.c_uint64 * 16)()
+        rc = _ck(_lib.rt1w_debug_stamps(self._h, C.byref(out), 1 if reset else 0))
+        return rc, [int(v) for v in out]
 
     def debug_eval(self, fn, a, b):
         a = np.ascontiguousarray(a, dtype=np.float64)

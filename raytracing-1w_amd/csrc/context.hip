@@ -20,16 +20,39 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <type_traits>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "rt1w.h"
+#ifdef RT_STAMPS
+/* DIAGNOSTIC BUILD (librt1w_stamps.so): per-wave cycle accounting by phase.  Buckets:
+ * 0 loop/other, 1 regeneration (new sample / new work item), 2 traversal, 3 hit record,
+ * 4 lambertian shading, 5 other shading, 6 sample bookkeeping.  Stamp values go only to
+ * g_stamp_total, which no render code reads. */
+__shared__ unsigned long long rt_stamp_acc[4][16];
+__shared__ unsigned long long rt_stamp_last[4];
+__device__ unsigned long long g_stamp_total[16];
+__device__ __forceinline__ void rt_stamp_fn(int k) {
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) {
+        int w = threadIdx.x >> 6;
+        rt_stamp_acc[w][k] += t - rt_stamp_last[w];
+        rt_stamp_last[w] = t;
+    }
+}
+#define RT_STAMP(k) rt_stamp_fn(k)
+#endif
 #include "rt_core.h"
 #include "scene.h"
 
 #define RT_BLOCK 256
+#ifndef RT_LANE_NODES
+#define RT_LANE_NODES 0 /* experiment (measured slower: +14 VGPRs and extra VALU): hot node words in registers, v_readlane fetch; only valid for scenes of <= 64 nodes */
+#endif
 
 namespace {
 
@@ -40,20 +63,60 @@ struct LdsStack {
     __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
 };
 
+/* Scene resident in the register file: lane i keeps the hot words (kind, skip, 6 doubles) of
+ * node i; v_readlane with the wave-uniform node index fetches them.  <= 64 nodes. */
+struct LaneNodes {
+    uint32_t w[14];
+    __device__ __forceinline__ void load(const RtNode* nodes, uint32_t n_nodes) {
+        uint32_t i = threadIdx.x & 63u;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + (i < n_nodes ? i : n_nodes - 1u));
+#pragma unroll
+        for (int k = 0; k < 14; ++k) w[k] = src[k];
+    }
+    __device__ __forceinline__ RtNodeHot hot(uint32_t n) const {
+        RtNodeHot h;
+        h.kind = (uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)n);
+        h.skip = (uint32_t)__builtin_amdgcn_readlane((int)w[1], (int)n);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w[2 + 2 * k], (int)n);
+            uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)w[3 + 2 * k], (int)n);
+            h.d[k] = rt_u2d(((uint64_t)hi << 32) | lo);
+        }
+        h.d[6] = 0.0;
+        return h;
+    }
+};
+
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 /* counters[0] = next work item, counters[1] = traced segments */
+#ifndef RT_SWEEP_WAVES
+#define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
+#endif
 template <class Cfg>
-__global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+__global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : 2) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                             unsigned long long* __restrict__ counters) {
     /* the sweep variants need no traversal stack (and no LDS at all) */
     __shared__ uint32_t stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
     LdsStack stk;
     stk.base = stack_mem + threadIdx.x;
     stk.sp = 0;
+#if RT_LANE_NODES
+    typename std::conditional<Cfg::sweep, LaneNodes, RtGlobalNodes>::type ns;
+    if constexpr (Cfg::sweep) ns.load(sc.nodes, sc.n_nodes); else ns.p = sc.nodes;
+#else
+    RtGlobalNodes ns{sc.nodes};
+#endif
 
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 16; ++k) rt_stamp_acc[threadIdx.x >> 6][k] = 0;
+        rt_stamp_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     const unsigned long long n_items = rt_item_count(f);
     const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
     unsigned long long item = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -66,6 +129,7 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RtSceneView sc, RtF
     unsigned long long segs = 0;
 
     for (;;) {
+        RT_STAMP(0);
         if (!path.alive) {
             if (have && s == s_end) {
                 double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
@@ -97,15 +161,21 @@ __global__ __launch_bounds__(RT_BLOCK) void rt_render_kernel(RtSceneView sc, RtF
             }
             if (!have) break; /* no work left: this lane retires */
             rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+            RT_STAMP(1);
         }
         segs += path.depth_left != 0u ? 1ull : 0ull;
-        rt_path_step<Cfg>(sc, path, stk);
+        rt_path_step<Cfg>(sc, ns, path, stk);
         if (!path.alive) {
             sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
             ++s;
         }
+        RT_STAMP(6);
     }
     if (segs) atomicAdd(&counters[1], segs);
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 16; ++k) atomicAdd(&g_stamp_total[k], rt_stamp_acc[threadIdx.x >> 6][k]);
+#endif
 }
 
 /* Sum the chunk partials of each pixel in chunk order; then Color::into_sampled
@@ -163,7 +233,7 @@ struct rt1w_context {
     int grid[RT_N_VARIANTS] = {0, 0, 0, 0};
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
-    uint32_t n_nodes = 0;
+    uint32_t n_nodes = 0, scope_depth = 0;
 };
 
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
@@ -211,7 +281,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
     int variant = c->variant;
     if (p->flags >> 8) {
         variant = (int)((p->flags >> 8) & 0xFFu) - 1;
-        if (!rt_variant_valid(variant, c->n_nodes, c->has_media, c->has_tex, c->has_msphere)) {
+        if (!rt_variant_valid(variant, c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth)) {
             rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
         }
     }
@@ -311,7 +381,8 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     }
     c->has_media = s->has_media; c->has_tex = s->has_tex; c->has_msphere = s->has_msphere;
     c->n_nodes = (uint32_t)s->flat_nodes.size();
-    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere);
+    c->scope_depth = s->scope_depth;
+    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth);
     *out = c;
     return RT1W_OK;
 }
@@ -357,6 +428,22 @@ int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, r
     if (!hip_ok(hipMemcpy(out_rgb, c->d_out, bytes, hipMemcpyDeviceToHost), "framebuffer copy")) return RT1W_ERR_DEVICE;
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT1W_OK;
+}
+
+int rt1w_debug_stamps(rt1w_context* c, uint64_t out[16], int reset) {
+    if (!c || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+#ifdef RT_STAMPS
+    (void)hipSetDevice(c->device);
+    unsigned long long h[16];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp_total), sizeof h);
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_total), z, sizeof z); }
+    return 1;
+#else
+    (void)reset;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    return 0;
+#endif
 }
 
 int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, double* out, uint64_t n) {

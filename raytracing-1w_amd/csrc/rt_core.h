@@ -27,6 +27,11 @@
 #include "rt_flat.h"
 
 #define RT_POP_FLAG 0x80000000u
+/* diagnostic build only (-DRT_STAMPS, never shipped): RT_STAMP(k) charges the wave's cycles
+ * since the previous stamp to bucket k */
+#ifndef RT_STAMP
+#define RT_STAMP(k) ((void)0)
+#endif
 #ifndef RT_STAT_VISIT
 #define RT_STAT_VISIT(kind) ((void)0) /* hook for offline visit statistics (tools only) */
 #endif
@@ -35,8 +40,12 @@
  * build runs one lane at a time */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_WAVE_ANY(p) (__ballot((p)) != 0ull)
+/* make a wave-uniform loaded value "arrived" here, so that the waitcnt pass does not
+ * carry a pending scalar load into the loop that follows */
+#define RT_SCALAR_READY(x) asm volatile("" ::"s"(x))
 #else
 #define RT_WAVE_ANY(p) (p)
+#define RT_SCALAR_READY(x) ((void)0)
 #endif
 
 struct RtRay { RtV3 o, d; double time; };
@@ -73,6 +82,28 @@ RT_HD bool rt_aabb_hit(const double* bb, RtV3 o, RtV3 inv, double t_min, double 
         if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
         t_min = t0 > t_min ? t0 : t_min;                 \
         t_max = t1 < t_max ? t1 : t_max;                 \
+        if (t_max <= t_min) return false;                \
+    }
+    RT_SLAB(bb[0], bb[3], o.x, inv.x)
+    RT_SLAB(bb[1], bb[4], o.y, inv.y)
+    RT_SLAB(bb[2], bb[5], o.z, inv.z)
+#undef RT_SLAB
+    return true;
+}
+
+/* The same test with the running interval kept by max/min instructions.  Identical result
+ * whenever t_min and t_max are not NaN on entry: `t0 > t_min ? t0 : t_min` keeps t_min when t0
+ * is NaN and so does maxNum; equal values or zeros of either sign give the same comparisons
+ * afterwards (t_min, t_max are not outputs).  Callers take the literal form when a NaN bound
+ * is present (a NaN root was accepted earlier -- reference behaviour, reproduced). */
+RT_HD bool rt_aabb_hit_fast(const double* bb, RtV3 o, RtV3 inv, double t_min, double t_max) {
+#define RT_SLAB(minv, maxv, ov, iv)                      \
+    {                                                    \
+        double t0 = ((minv) - (ov)) * (iv);              \
+        double t1 = ((maxv) - (ov)) * (iv);              \
+        if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
+        t_min = __builtin_fmax(t0, t_min);               \
+        t_max = __builtin_fmin(t1, t_max);               \
         if (t_max <= t_min) return false;                \
     }
     RT_SLAB(bb[0], bb[3], o.x, inv.x)
@@ -261,6 +292,36 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
     rt_scope_out(nodes[c.s0], r1, h);
 }
 
+/* static sphere and the three rects, from the hot half of the record (same operations as rt_prim_t) */
+RT_HD bool rt_prim_hot_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d, double t_min, double t_max, double& t_out) {
+    if (kind >= RT_XY) {
+        double oa = kind == RT_XY ? o.z : (kind == RT_XZ ? o.y : o.x);
+        double da = kind == RT_XY ? d.z : (kind == RT_XZ ? d.y : d.x);
+        double ob = kind == RT_YZ ? o.y : o.x;
+        double db = kind == RT_YZ ? d.y : d.x;
+        double oc = kind == RT_XY ? o.y : o.z;
+        double dc = kind == RT_XY ? d.y : d.z;
+        double t = (nd.d[4] - oa) / da;
+        if (t < t_min || t > t_max) return false;
+        double b = ob + t * db;
+        double c = oc + t * dc;
+        if (b < nd.d[0] || b > nd.d[1] || c < nd.d[2] || c > nd.d[3]) return false;
+        t_out = t;
+        return true;
+    }
+    return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t_out);
+}
+
+/* Where the sweep gets the hot half of node n (n is wave-uniform):
+ *  - RtGlobalNodes: from memory (scalar loads on the GPU);
+ *  - a lane-resident source (context.hip, scenes of <= 64 nodes): lane i of every wave keeps
+ *    node i's hot words in registers for the whole kernel and node n is read with
+ *    v_readlane -- the traversal then touches no memory at all. */
+struct RtGlobalNodes {
+    const RtNode* p;
+    RT_HD RtNodeHot hot(uint32_t n) const { return *reinterpret_cast<const RtNodeHot*>(p + n); }
+};
+
 /* ----------------------------------------------------------- traversal -- */
 
 RT_HD RtV3 rt_inv3(RtV3 d) { return rt_v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
@@ -274,7 +335,8 @@ RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_
     rec1 = rt_max(rec1, 0.0);
     double ray_length = rt_mag(d);
     double distance_inside_boundary = (rec2 - rec1) * ray_length;
-    double hit_distance = nd.d[0] * rt_log(rt_gen_f64(rng));
+    rt_rng_reserve(rng, rt_rng_need_u64(rng));
+    double hit_distance = nd.d[0] * rt_log(rt_take_f64(rng));
     if (hit_distance > distance_inside_boundary) return false;
     t_out = rec1 + hit_distance / ray_length;
     return true;
@@ -291,7 +353,8 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
     const RtNode* nodes = sc.nodes;
     RtRayOD w; w.o = world.o; w.d = world.d;
     RtRayOD cur = w;
-    RtV3 inv = rt_inv3(cur.d);
+    const RtV3 inv_w = rt_inv3(w.d);
+    RtV3 inv = inv_w;
     uint32_t scope = RT_NONE;
     double best_t = t_max;
     uint32_t best_prim = RT_NONE, best_scope = RT_NONE;
@@ -303,14 +366,17 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
             /* leaving a wrapper: back to the parent's ray (recomputed from the
              * outer ray by the same operations that produced it, hence the same bits) */
             scope = nodes[e & ~RT_POP_FLAG].b;
-            cur = rt_ray_in_scope(nodes, scope, w);
-            inv = rt_inv3(cur.d);
+            if (scope == RT_NONE) { cur = w; inv = inv_w; }
+            else { cur = rt_ray_in_scope(nodes, scope, w); inv = rt_inv3(cur.d); }
             continue;
         }
         const RtNode& nd = nodes[e];
         uint32_t kind = nd.kind;
         if (kind <= RT_BVH1) {
-            if (rt_aabb_hit(nd.d, cur.o, inv, t_min, best_t)) {
+            bool hit;
+            if (RT_WAVE_ANY(rt_isnan(t_min) || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, cur.o, inv, t_min, best_t);
+            else hit = rt_aabb_hit_fast(nd.d, cur.o, inv, t_min, best_t);
+            if (hit) {
                 if (kind == RT_BVH2) stk.push(nd.b);
                 stk.push(nd.a);
             }
@@ -350,71 +416,91 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
  * divergence between node kinds), and lanes that do not visit node n just sit out
  * that step.  Every lane still visits exactly the nodes the stack walk would, in
  * the same order, with the same arithmetic. */
-template <class Cfg, bool MEDIA>
-RT_HD bool rt_traverse_sweep(const RtSceneView& sc, uint32_t root, const RtRay& world, double t_min,
+template <class Cfg, bool MEDIA, class NS>
+RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, double& out_t, uint32_t& out_prim, uint32_t& out_scope) {
     const RtNode* nodes = sc.nodes;
     RtRayOD w; w.o = world.o; w.d = world.d;
     RtRayOD cur_ray = w;
-    RtV3 inv = rt_inv3(cur_ray.d);
+    const RtV3 inv_w = rt_inv3(w.d);
+    RtV3 inv = inv_w;
     uint32_t scope = RT_NONE, scope_end = RT_NONE;
     double best_t = t_max;
     uint32_t best_prim = RT_NONE, best_scope = RT_NONE;
-    const uint32_t end = nodes[root].skip;
+    const bool tmin_nan = rt_isnan(t_min);
+    const uint32_t end = ns.hot(root).skip;
     uint32_t cur = root;
+    RT_STAMP(8);
     for (uint32_t n = root; n < end; ++n) {
+        const RtNodeHot nd = ns.hot(n);
         /* lanes whose wrapper's subtree ended before n go back to the parent's ray */
         if (RT_WAVE_ANY(scope_end <= n)) {
-            while (scope_end <= n) {
-                scope = nodes[scope].b;
-                scope_end = (scope == RT_NONE) ? RT_NONE : nodes[scope].skip;
-                cur_ray = rt_ray_in_scope(nodes, scope, w);
-                inv = rt_inv3(cur_ray.d);
+            if (scope_end <= n) {
+                do {
+                    scope = nodes[scope].b;
+                    scope_end = (scope == RT_NONE) ? RT_NONE : nodes[scope].skip;
+                } while (scope_end <= n);
+                /* the parent's ray, recomputed from the outer ray by the operations that made it */
+                if (scope == RT_NONE) { cur_ray = w; inv = inv_w; }
+                else { cur_ray = rt_ray_in_scope(nodes, scope, w); inv = rt_inv3(cur_ray.d); }
             }
         }
+        RT_STAMP(9);
         bool active = (cur == n);
-        if (!RT_WAVE_ANY(active)) continue;
-        const RtNode& nd = nodes[n];
+        if (!RT_WAVE_ANY(active)) { RT_STAMP(10); continue; }
         const uint32_t kind = nd.kind;
         if (active) {
             RT_STAT_VISIT(kind);
             if (kind <= RT_BVH1) {
-                cur = rt_aabb_hit(nd.d, cur_ray.o, inv, t_min, best_t) ? n + 1u : nd.skip;
+                bool hit;
+                if (RT_WAVE_ANY(tmin_nan || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, cur_ray.o, inv, t_min, best_t);
+                else hit = rt_aabb_hit_fast(nd.d, cur_ray.o, inv, t_min, best_t);
+                cur = hit ? n + 1u : nd.skip;
             } else if (kind <= RT_YZ) {
                 double t;
-                if (rt_prim_t<Cfg>(nd, kind, cur_ray.o, cur_ray.d, world.time, t_min, best_t, t)) {
-                    best_t = t; best_prim = n; best_scope = scope;
-                }
+                bool hit;
+                if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[n], kind, cur_ray.o, cur_ray.d, world.time, t_min, best_t, t);
+                else hit = rt_prim_hot_t(nd, kind, cur_ray.o, cur_ray.d, t_min, best_t, t);
+                if (hit) { best_t = t; best_prim = n; best_scope = scope; }
                 cur = n + 1u;
             } else if (kind <= RT_FLIP) {
                 scope = n; scope_end = nd.skip;
-                if (kind != RT_FLIP) {
-                    cur_ray = rt_scope_in(nd, cur_ray);
-                    if (kind == RT_ROTATE_Y) inv = rt_inv3(cur_ray.d);
+                if (kind == RT_TRANSLATE) {
+                    cur_ray.o = cur_ray.o - rt_v3(nd.d[0], nd.d[1], nd.d[2]);
+                } else if (kind == RT_ROTATE_Y) {
+                    double sn = nd.d[0], cs = nd.d[1];
+                    RtV3 o = cur_ray.o, d = cur_ray.d;
+                    cur_ray.o.x = cs * o.x - sn * o.z;
+                    cur_ray.o.z = sn * o.x + cs * o.z;
+                    cur_ray.d.x = cs * d.x - sn * d.z;
+                    cur_ray.d.z = sn * d.x + cs * d.z;
+                    inv = rt_inv3(cur_ray.d);
                 }
                 cur = n + 1u;
             } else {
                 if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
+                    const RtNode& full = nodes[n];
                     RtRay br; br.o = cur_ray.o; br.d = cur_ray.d; br.time = world.time;
                     double t1, t2, t; uint32_t p_, s_;
-                    if (rt_traverse_sweep<Cfg, false>(sc, nd.a, br, -RT_INF, RT_INF, rng, t1, p_, s_) &&
-                        rt_traverse_sweep<Cfg, false>(sc, nd.a, br, t1 + 0.0001, RT_INF, rng, t2, p_, s_) &&
-                        rt_medium_t(nd, cur_ray.d, t1, t2, t_min, best_t, rng, t)) {
+                    if (rt_traverse_sweep<Cfg, false>(sc, ns, full.a, br, -RT_INF, RT_INF, rng, t1, p_, s_) &&
+                        rt_traverse_sweep<Cfg, false>(sc, ns, full.a, br, t1 + 0.0001, RT_INF, rng, t2, p_, s_) &&
+                        rt_medium_t(full, cur_ray.d, t1, t2, t_min, best_t, rng, t)) {
                         best_t = t; best_prim = n; best_scope = scope;
                     }
                 }
                 cur = nd.skip;
             }
         }
+        RT_STAMP(kind <= RT_BVH1 ? 11 : (kind <= RT_YZ ? 12 : 13));
     }
     out_t = best_t; out_prim = best_prim; out_scope = best_scope;
     return best_prim != RT_NONE;
 }
 
-template <class Cfg, class Stack>
-RT_HD bool rt_closest_hit(const RtSceneView& sc, const RtRay& ray, double t_min, double t_max, RtRng& rng,
+template <class Cfg, class Stack, class NS>
+RT_HD bool rt_closest_hit(const RtSceneView& sc, const NS& ns, const RtRay& ray, double t_min, double t_max, RtRng& rng,
                           Stack& stk, double& t, uint32_t& prim, uint32_t& scope) {
-    if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, sc.root, ray, t_min, t_max, rng, t, prim, scope);
+    if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, t, prim, scope);
     else return rt_traverse_stack<Cfg, true>(sc, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
 }
 
@@ -502,9 +588,11 @@ RT_HD RtV3 rt_texture(const RtSceneView& sc, uint32_t tex, double u, double v, R
 /* math.rs:6-18 */
 RT_HD RtV3 rt_random_in_unit_sphere(RtRng& rng) {
     for (;;) {
-        double x = rt_gen_range(rng, -1.0, 1.0);
-        double y = rt_gen_range(rng, -1.0, 1.0);
-        double z = rt_gen_range(rng, -1.0, 1.0);
+        rt_rng_reserve(rng, rt_rng_need_2u64(rng));
+        double x = rt_take_range(rng, -1.0, 1.0);
+        double y = rt_take_range(rng, -1.0, 1.0);
+        rt_rng_reserve(rng, rt_rng_need_u64(rng));
+        double z = rt_take_range(rng, -1.0, 1.0);
         RtV3 v = rt_v3(x, y, z);
         if (rt_mag2(v) < 1.0) return v;
     }
@@ -512,16 +600,17 @@ RT_HD RtV3 rt_random_in_unit_sphere(RtRng& rng) {
 /* math.rs:30-37 */
 RT_HD RtV3 rt_random_in_unit_disk(RtRng& rng) {
     for (;;) {
-        double x = rt_gen_range(rng, -1.0, 1.0);
-        double y = rt_gen_range(rng, -1.0, 1.0);
+        rt_rng_reserve(rng, rt_rng_need_2u64(rng));
+        double x = rt_take_range(rng, -1.0, 1.0);
+        double y = rt_take_range(rng, -1.0, 1.0);
         RtV3 p = rt_v3(x, y, 0.0);
         if (rt_mag2(p) < 1.0) return p;
     }
 }
-/* math.rs:39-49 */
+/* math.rs:39-49 (caller has reserved two 64-bit draws) */
 RT_HD RtV3 rt_random_cosine_direction(RtRng& rng) {
-    double r1 = rt_gen_f64(rng);
-    double r2 = rt_gen_f64(rng);
+    double r1 = rt_take_f64(rng);
+    double r2 = rt_take_f64(rng);
     double z = rt_sqrt(1.0 - r2);
     double phi = 2.0 * RT_PI * r1;
     double s, c;
@@ -529,10 +618,10 @@ RT_HD RtV3 rt_random_cosine_direction(RtRng& rng) {
     double sr2 = rt_sqrt(r2);
     return rt_v3(c * sr2, s * sr2, z);
 }
-/* math.rs:51-65 */
+/* math.rs:51-65 (caller has reserved two 64-bit draws) */
 RT_HD RtV3 rt_random_to_sphere(double radius, double distance_squared, RtRng& rng) {
-    double r1 = rt_gen_f64(rng);
-    double r2 = rt_gen_f64(rng);
+    double r1 = rt_take_f64(rng);
+    double r2 = rt_take_f64(rng);
     double z = 1.0 + r2 * (rt_sqrt(1.0 - radius * radius / distance_squared) - 1.0);
     double phi = 2.0 * RT_PI * r1;
     double s, c;
@@ -578,11 +667,12 @@ RT_HD double rt_light_pdf_value(const RtNode& l, RtV3 o, RtV3 v) {
     }
     return 0.0;
 }
-/* Hittable::random of one light: aarect.rs:140-147, sphere.rs:92-99, default (1,0,0) */
+/* Hittable::random of one light: aarect.rs:140-147, sphere.rs:92-99, default (1,0,0)
+ * (caller has reserved two 64-bit draws) */
 RT_HD RtV3 rt_light_random(const RtNode& l, RtV3 o, RtRng& rng) {
     if (l.kind == RT_XZ) {
-        double x = rt_gen_range(rng, l.d[0], l.d[1]);
-        double z = rt_gen_range(rng, l.d[2], l.d[3]);
+        double x = rt_take_range(rng, l.d[0], l.d[1]);
+        double z = rt_take_range(rng, l.d[2], l.d[3]);
         return rt_v3(x, l.d[4], z) - o;
     }
     if (l.kind == RT_SPHERE) {
@@ -622,14 +712,16 @@ RT_HD double rt_reflectance(double cosine, double ref_idx) {                  /*
 RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, uint32_t j,
                          uint32_t sample, RtPath& p) {
     p.rng = rt_rng_pixel_sample((uint64_t)j * f.width + i, sample, f.global_seed);
-    double u = ((double)i + rt_gen_f64(p.rng)) / (double)(f.width - 1u);
-    double v = ((double)j + rt_gen_f64(p.rng)) / (double)(f.height - 1u);
+    rt_rng_reserve(p.rng, 4u);
+    double u = ((double)i + rt_take_f64(p.rng)) / (double)(f.width - 1u);
+    double v = ((double)j + rt_take_f64(p.rng)) / (double)(f.height - 1u);
     const RtCamera& c = sc.camera;
     RtV3 rd = c.lens_radius * rt_random_in_unit_disk(p.rng);
     RtV3 offset = c.u * rd.x + c.v * rd.y;
     p.ray.o = c.origin + offset;
     p.ray.d = c.lower_left_corner + u * c.horizontal + v * c.vertical - c.origin - offset;
-    p.ray.time = rt_gen_range(p.rng, c.time0, c.time1);
+    rt_rng_reserve(p.rng, rt_rng_need_u64(p.rng));
+    p.ray.time = rt_take_range(p.rng, c.time0, c.time1);
     p.beta = rt_v3(1.0, 1.0, 1.0);
     p.radiance = rt_v3(0.0, 0.0, 0.0);
     p.depth_left = f.max_depth;
@@ -643,21 +735,25 @@ RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, ui
  * beta = beta (.) W / pdf.  Every terminal adds beta (.) value -- including the zero
  * of depth exhaustion (main.rs:59-61) -- so a non-finite beta poisons the sample
  * exactly as it does through the reference's multiplications. */
-template <class Cfg, class Stack>
-RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
+template <class Cfg, class Stack, class NS>
+RT_HD void rt_path_step(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& stk) {
     if (p.depth_left == 0u) {
         p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
         p.alive = false;
         return;
     }
     double t; uint32_t prim, scope;
-    if (!rt_closest_hit<Cfg>(sc, p.ray, 0.001, RT_INF, p.rng, stk, t, prim, scope)) {
+    RT_STAMP(0);
+    bool found_ = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, t, prim, scope);
+    RT_STAMP(2);
+    if (!found_) {
         p.radiance = p.radiance + rt_mul(p.beta, sc.background);
         p.alive = false;
         return;
     }
     RtHit h;
     rt_finish_hit<Cfg>(sc, p.ray, prim, scope, t, h);
+    RT_STAMP(3);
     const RtMaterial& m = sc.materials[h.mat];
     uint32_t mk = m.kind & 0xFFu;
 
@@ -681,10 +777,13 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
         double pdf;
         if (sc.n_lights > 0u) {
             /* MixturePdf::generate pdf.rs:62-68, p0 = HittablePdf{lights} */
-            if (rt_gen_bool(p.rng)) {
+            rt_rng_fill(p.rng);
+            if (rt_take_bool(p.rng)) {
                 uint32_t li = rt_gen_below(p.rng, sc.n_lights); /* choose, hittable.rs:153 */
+                rt_rng_reserve(p.rng, rt_rng_need_2u64(p.rng));
                 dir = rt_light_random(sc.lights[li], h.p, p.rng);
             } else {
+                rt_rng_reserve(p.rng, rt_rng_need_2u64(p.rng));
                 dir = rt_onb_local(uvw, rt_random_cosine_direction(p.rng)); /* pdf.rs:42-44 */
             }
             /* MixturePdf::value pdf.rs:58-60 */
@@ -692,6 +791,7 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
             double p1 = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0); /* pdf.rs:37-40 */
             pdf = 0.5 * p0 + 0.5 * p1;
         } else {
+            rt_rng_reserve(p.rng, rt_rng_need_2u64(p.rng));
             dir = rt_onb_local(uvw, rt_random_cosine_direction(p.rng));
             pdf = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0);
         }
@@ -700,6 +800,7 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
         p.beta = rt_mul(p.beta, attenuation * spdf) / pdf;
         p.ray.o = h.p; p.ray.d = dir;
         p.ray.time = h.t; /* main.rs:86: time = hit_record.t (reference quirk Q1) */
+        RT_STAMP(4);
     } else if (mk == RT_MAT_METAL) {
         /* Metal::scatter material.rs:99-111 */
         RtV3 reflected = rt_reflect(rt_normalize(p.ray.d), h.n);
@@ -714,7 +815,7 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
         double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
         bool cannot_refract = refraction_ratio * sin_theta > 1.0;
         RtV3 dir;
-        if (cannot_refract || rt_reflectance(cos_theta, refraction_ratio) > rt_gen_f64(p.rng))
+        if (cannot_refract || rt_reflectance(cos_theta, refraction_ratio) > rt_gen_f64(p.rng)) /* checked draw: rarely-run site */
             dir = rt_reflect(unit_direction, h.n);
         else
             dir = rt_refract(unit_direction, h.n, refraction_ratio);
@@ -733,6 +834,7 @@ RT_HD void rt_path_step(const RtSceneView& sc, RtPath& p, Stack& stk) {
         return;
     }
     p.depth_left -= 1u;
+    RT_STAMP(5);
 }
 
 /* ----------------------------------------------------------------- color -- */

@@ -33,15 +33,24 @@ enum {
                          (src/hittable.rs:66-71 defaults) */
 };
 
+/* Layout: the fields a traversal step reads (kind, skip and the first 7 doubles: a whole
+ * AABB, rect, sphere or wrapper) are the first 64 bytes -- one s_load_dwordx16 when the
+ * index is wave-uniform (sweep), four dwordx4 when it is per-lane (stack). */
 struct RtNode {
-    double d[9];
     uint32_t kind;
+    uint32_t skip; /* nodes are stored in depth-first pre-order: [index, skip) is this node's subtree */
+    double d[9];
     uint32_t mat;
     uint32_t a;
     uint32_t b;
-    uint32_t skip; /* nodes are stored in depth-first pre-order: [index, skip) is this node's subtree */
     uint32_t pad;
 }; /* 96 bytes */
+/* the first 64 bytes of an RtNode */
+struct RtNodeHot {
+    uint32_t kind;
+    uint32_t skip;
+    double d[7];
+};
 
 /* material kinds: every `impl Material` */
 enum {
@@ -122,28 +131,29 @@ struct RtFrame {
 
 /* compile-time feature set of a kernel variant: code for absent features is not
  * generated, which is what keeps the register budget of the simple scenes low */
-template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_>
+template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_, int SCOPE_DEPTH_ = 3>
 struct RtCfg {
+    static constexpr int scope_depth = SCOPE_DEPTH_; /* deepest wrapper nesting the sweep variant handles */
     static constexpr bool media = MEDIA_;     /* scene contains ConstantMedium nodes */
     static constexpr bool tex = TEX_;         /* scene has non-solid textures (checker/noise/image) */
     static constexpr bool msphere = MSPHERE_; /* scene has MovingSphere primitives */
     static constexpr bool sweep = SWEEP_;     /* stackless pre-order sweep instead of the LDS stack */
 };
 /* the variants that are built (host picks the cheapest one that covers the scene) */
-typedef RtCfg<false, false, false, true> RtCfgV0; /* small scene, solid colours only, no media, no moving spheres (Cornell box) */
+typedef RtCfg<false, false, false, true, 2> RtCfgV0; /* small scene, solid colours only, no media, no moving spheres (Cornell box) */
 typedef RtCfg<true, true, true, true> RtCfgV1;    /* small scene, every feature */
 typedef RtCfg<false, true, true, false> RtCfgV2;  /* large scene without media (random_scene) */
 typedef RtCfg<true, true, true, false> RtCfgV3;   /* large scene, every feature (final_scene) */
 #define RT_N_VARIANTS 4
 /* cheapest valid variant for a scene; `force` >= 0 overrides when valid */
-inline int rt_pick_variant(uint32_t n_nodes, bool media, bool tex, bool msphere) {
-    if (n_nodes <= RT_SWEEP_MAX_NODES) return (!media && !tex && !msphere) ? 0 : 1;
+inline int rt_pick_variant(uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth) {
+    if (n_nodes <= RT_SWEEP_MAX_NODES) return (!media && !tex && !msphere && scope_depth <= 2u) ? 0 : 1;
     return media ? 3 : 2;
 }
-inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool msphere) {
+inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth) {
     (void)n_nodes;
     switch (v) {
-        case 0: return !media && !tex && !msphere;
+        case 0: return !media && !tex && !msphere && scope_depth <= 2u;
         case 1: return true;
         case 2: return !media;
         case 3: return true;

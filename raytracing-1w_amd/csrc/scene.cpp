@@ -624,7 +624,7 @@ int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
     out->has_media = s->has_media ? 1u : 0u;
     out->has_textures = s->has_tex ? 1u : 0u;
     out->has_moving = s->has_msphere ? 1u : 0u;
-    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere);
+    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere, s->scope_depth);
     out->bytes = s->flat_nodes.size() * sizeof(RtNode) + s->flat_lights.size() * sizeof(RtNode) +
                  s->materials.size() * sizeof(RtMaterial) + s->textures.size() * sizeof(RtTexture) +
                  s->perlin.size() * sizeof(RtPerlin) + s->images.size();

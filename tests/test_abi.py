@@ -100,7 +100,7 @@ def test_flattened_cornell_structure(rt):
     sc = rt.Scene.reference(5, build_seed=1)
     info = sc.info()
     nodes = sc.flat(0).view(np.uint32).reshape(-1, 24)
-    kinds = nodes[:, 18]
+    kinds = nodes[:, 0]
     assert info["n_nodes"] == 30 and info["n_lights"] == 2 and info["has_media"] == 0
     assert (kinds <= 1).sum() == 14                  # BVH nodes: 7 top + 7 in the box
     assert ((kinds >= 2) & (kinds <= 6)).sum() == 13 # 5 walls + light + 6 box sides + sphere
