@@ -200,6 +200,13 @@ RT_HD uint32_t rt_gen_below(RtRng& r, uint32_t n) {
     }
 }
 
+/* conversions of one 64-bit draw (rand 0.8 Standard f64 / UniformFloat) */
+RT_HD double rt_f64_from_bits(uint64_t q) { return (double)(q >> 11) * (1.0 / 9007199254740992.0); }
+RT_HD double rt_range_from_bits(uint64_t q, double low, double high) {
+    double scale = high - low;
+    double v12 = rt_u2d((q >> 12) | 0x3FF0000000000000ull);
+    return (v12 - 1.0) * scale + low;
+}
 /* ---- the same shapes over reserved words (device core; see rt_rng_reserve) ---- */
 RT_HD double rt_take_f64(RtRng& r) { return (double)(rt_take_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
 RT_HD double rt_take_range(RtRng& r, double low, double high) {

@@ -775,25 +775,63 @@ RT_HD void rt_path_step(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& s
         RtOnb uvw = rt_onb_from_w(h.n);
         RtV3 dir;
         double pdf;
+        /* MixturePdf::generate pdf.rs:62-68 (p0 = HittablePdf{lights}, p1 = CosinePdf), or CosinePdf alone.
+         * The cosine lobe (math.rs:39-49), the sphere light (sphere.rs:92-99 -> math.rs:51-65) and the
+         * rect light (aarect.rs:140-147) each consume two 64-bit draws, so the draws are taken once for
+         * the three cases and only the conversion differs; cosine and sphere share one sincos. */
+        uint32_t lk = RT_NONE; /* RT_NONE: cosine lobe */
+        uint32_t li = 0u;
         if (sc.n_lights > 0u) {
-            /* MixturePdf::generate pdf.rs:62-68, p0 = HittablePdf{lights} */
             rt_rng_fill(p.rng);
             if (rt_take_bool(p.rng)) {
-                uint32_t li = rt_gen_below(p.rng, sc.n_lights); /* choose, hittable.rs:153 */
-                rt_rng_reserve(p.rng, rt_rng_need_2u64(p.rng));
-                dir = rt_light_random(sc.lights[li], h.p, p.rng);
-            } else {
-                rt_rng_reserve(p.rng, rt_rng_need_2u64(p.rng));
-                dir = rt_onb_local(uvw, rt_random_cosine_direction(p.rng)); /* pdf.rs:42-44 */
+                li = rt_gen_below(p.rng, sc.n_lights); /* choose, hittable.rs:153 */
+                lk = sc.lights[li].kind;
             }
-            /* MixturePdf::value pdf.rs:58-60 */
-            double p0 = rt_lights_pdf_value(sc, h.p, dir);
-            double p1 = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0); /* pdf.rs:37-40 */
-            pdf = 0.5 * p0 + 0.5 * p1;
-        } else {
+        }
+        if (lk == RT_NONE || lk == RT_XZ || lk == RT_SPHERE) {
             rt_rng_reserve(p.rng, rt_rng_need_2u64(p.rng));
-            dir = rt_onb_local(uvw, rt_random_cosine_direction(p.rng));
-            pdf = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0);
+            uint64_t q1 = rt_take_u64(p.rng);
+            uint64_t q2 = rt_take_u64(p.rng);
+            if (lk == RT_XZ) {
+                const RtNode& l = sc.lights[li];
+                double x = rt_range_from_bits(q1, l.d[0], l.d[1]);
+                if (!(x < l.d[1])) { /* rounding onto `high`: the retry takes the next draw (rand 0.8 sample_single) */
+                    x = rt_range_from_bits(q2, l.d[0], l.d[1]);
+                    while (!(x < l.d[1])) x = rt_range_from_bits(rt_next_u64(p.rng), l.d[0], l.d[1]);
+                    q2 = rt_next_u64(p.rng);
+                }
+                double z = rt_range_from_bits(q2, l.d[2], l.d[3]);
+                while (!(z < l.d[3])) z = rt_range_from_bits(rt_next_u64(p.rng), l.d[2], l.d[3]);
+                dir = rt_v3(x, l.d[4], z) - h.p;
+            } else {
+                double r1 = rt_f64_from_bits(q1);
+                double r2 = rt_f64_from_bits(q2);
+                double phi = 2.0 * RT_PI * r1;
+                double sn, cs;
+                rt_sincos(phi, sn, cs);
+                if (lk == RT_SPHERE) {
+                    const RtNode& l = sc.lights[li];
+                    RtV3 direction = rt_v3(l.d[0], l.d[1], l.d[2]) - h.p;
+                    double distance_squared = rt_mag2(direction);
+                    RtOnb lw = rt_onb_from_w(direction);
+                    double z = 1.0 + r2 * (rt_sqrt(1.0 - l.d[3] * l.d[3] / distance_squared) - 1.0);
+                    double q = rt_sqrt(1.0 - z * z);
+                    dir = rt_onb_local(lw, rt_v3(cs * q, sn * q, z));
+                } else {
+                    double z = rt_sqrt(1.0 - r2);
+                    double sr2 = rt_sqrt(r2);
+                    dir = rt_onb_local(uvw, rt_v3(cs * sr2, sn * sr2, z));
+                }
+            }
+        } else {
+            dir = rt_v3(1.0, 0.0, 0.0); /* Hittable::random default, hittable.rs:69-71 */
+        }
+        double p1 = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0); /* CosinePdf::value pdf.rs:37-40 */
+        if (sc.n_lights > 0u) {
+            double p0 = rt_lights_pdf_value(sc, h.p, dir);
+            pdf = 0.5 * p0 + 0.5 * p1; /* MixturePdf::value pdf.rs:58-60 */
+        } else {
+            pdf = p1;
         }
         /* Lambertian::scattering_pdf material.rs:82-91 */
         double spdf = rt_max(rt_dot(h.n, rt_normalize(dir)) / RT_PI, 0.0);
