@@ -37,7 +37,7 @@ def cpu_baseline(cores):
     _, st = sc.render(W, H, spp, max_depth=DEPTH, threads=cores)
     dt = time.time() - t0
     # scale the sample to ~12 s of CPU work
-    spp2 = max(4, min(64, int(spp * 12.0 / max(dt, 1e-3))))
+    spp2 = max(4, min(512, int(spp * 12.0 / max(dt, 1e-3))))
     t0 = time.time()
     _, st = sc.render(W, H, spp2, max_depth=DEPTH, threads=cores)
     dt = time.time() - t0

@@ -139,6 +139,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out);
 void rt1w_context_destroy(rt1w_context* c);
 
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
+#define RT1W_UNSORTED 2u  /* tests/ablation: use the kernel without workgroup-level path reordering */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
 typedef struct rt1w_render_params {
@@ -159,7 +160,8 @@ typedef struct rt1w_stats {
     double total_ms;       /* host wall time of the call incl. device->host copy */
     uint32_t chunk, n_chunks;
     uint32_t grid, block;
-    uint32_t variant, reserved;
+    uint32_t variant;      /* kernel variant used (V0..V3) */
+    uint32_t sorted;       /* 1: the reordering kernel ran */
 } rt1w_stats;
 
 /* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */

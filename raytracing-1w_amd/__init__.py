@@ -32,6 +32,7 @@ _lib = C.CDLL(LIB_PATH)
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_STATE = -1, -2, -3, -4, -5
 OUT_SUM = 1
+UNSORTED = 2
 
 
 class Rt1wError(RuntimeError):
@@ -49,7 +50,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("chunk", C.c_uint32), ("n_chunks", C.c_uint32),
-                ("grid", C.c_uint32), ("block", C.c_uint32), ("variant", C.c_uint32), ("reserved", C.c_uint32)]
+                ("grid", C.c_uint32), ("block", C.c_uint32), ("variant", C.c_uint32), ("sorted", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
@@ -294,24 +295,24 @@ class Context:
     __del__ = close
 
     @staticmethod
-    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None):
+    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        flags = (OUT_SUM if out_sum else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        flags = (OUT_SUM if out_sum else 0) | (UNSORTED if unsorted else 0) | (((variant + 1) << 8) if variant is not None else 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags)
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-               variant=None):
+               variant=None, unsorted=False):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict)."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted)
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
         st = Stats()
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
     def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0,
-                      out_sum=False, variant=None):
+                      out_sum=False, variant=None, unsorted=False):
         """Same, into device memory `d_ptr` (int address, e.g. torch tensor .data_ptr())."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted)
         st = Stats()
         _ck(_lib.rt1w_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.byref(st)))
         return {n: getattr(st, n) for n, _ in Stats._fields_}

@@ -32,6 +32,9 @@
 #ifndef RT_STAMP
 #define RT_STAMP(k) ((void)0)
 #endif
+#ifndef RT_STAT_MAT
+#define RT_STAT_MAT(mk) ((void)0)
+#endif
 #ifndef RT_STAT_VISIT
 #define RT_STAT_VISIT(kind) ((void)0) /* hook for offline visit statistics (tools only) */
 #endif
@@ -735,27 +738,58 @@ RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, ui
  * beta = beta (.) W / pdf.  Every terminal adds beta (.) value -- including the zero
  * of depth exhaustion (main.rs:59-61) -- so a non-finite beta poisons the sample
  * exactly as it does through the reference's multiplications. */
+/* The closest hit found by the first half of a step, and what the second half will do with
+ * it: the class is the sort key of the workgroup-level reordering (context.hip). */
+struct RtTrace {
+    double t;
+    uint32_t prim, scope;
+    uint32_t cls; /* RT_CLS_* */
+};
+enum { RT_CLS_LAMBERT = 0, RT_CLS_DIELECTRIC = 1, RT_CLS_METAL = 2, RT_CLS_OTHER = 3, RT_CLS_TERMINAL = 4, RT_CLS_IDLE = 5, RT_N_CLS = 6 };
+
+/* first half of one level of ray_color: depth check (main.rs:59-61) and world.hit (main.rs:62) */
 template <class Cfg, class Stack, class NS>
-RT_HD void rt_path_step(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& stk) {
+RT_HD RtTrace rt_path_trace(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& stk) {
+    RtTrace tr;
+    tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
+    if (p.depth_left == 0u) return tr;
+    RT_STAMP(0);
+    bool found = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, tr.t, tr.prim, tr.scope);
+    RT_STAMP(2);
+    if (!found) { tr.prim = RT_NONE; return tr; }
+    uint32_t mk = sc.materials[sc.nodes[tr.prim].mat].kind & 0xFFu;
+    tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT
+           : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
+           : mk == RT_MAT_METAL ? RT_CLS_METAL
+           : mk == RT_MAT_ISOTROPIC ? RT_CLS_OTHER : RT_CLS_TERMINAL;
+    return tr;
+}
+
+/* second half: emitted / scatter / the next ray (main.rs:63-115).  The recursion
+ * L = emitted + W (.) L'/pdf  is carried as  radiance += beta (.) emitted,
+ * beta = beta (.) W / pdf.  Every terminal adds beta (.) value -- including the zero
+ * of depth exhaustion (main.rs:59-61) -- so a non-finite beta poisons the sample
+ * exactly as it does through the reference's multiplications. */
+template <class Cfg>
+RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
     if (p.depth_left == 0u) {
         p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
         p.alive = false;
         return;
     }
-    double t; uint32_t prim, scope;
-    RT_STAMP(0);
-    bool found_ = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, t, prim, scope);
-    RT_STAMP(2);
-    if (!found_) {
+    if (tr.prim == RT_NONE) {
         p.radiance = p.radiance + rt_mul(p.beta, sc.background);
         p.alive = false;
         return;
     }
+    const double t = tr.t;
+    const uint32_t prim = tr.prim, scope = tr.scope;
     RtHit h;
     rt_finish_hit<Cfg>(sc, p.ray, prim, scope, t, h);
     RT_STAMP(3);
     const RtMaterial& m = sc.materials[h.mat];
     uint32_t mk = m.kind & 0xFFu;
+    RT_STAT_MAT(mk);
 
     /* emitted: DiffuseLight material.rs:168-181 (front face only); every other
      * material returns the default (0,0,0) (material.rs:40-49), whose addition in
@@ -873,6 +907,13 @@ RT_HD void rt_path_step(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& s
     }
     p.depth_left -= 1u;
     RT_STAMP(5);
+}
+
+/* One level of ray_color (main.rs:51-116; with no lights :118-190) */
+template <class Cfg, class Stack, class NS>
+RT_HD void rt_path_step(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& stk) {
+    RtTrace tr = rt_path_trace<Cfg>(sc, ns, p, stk);
+    rt_path_shade<Cfg>(sc, p, tr);
 }
 
 /* ----------------------------------------------------------------- color -- */

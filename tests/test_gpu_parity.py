@@ -80,6 +80,20 @@ def test_gpu_kernel_variants_agree(rt, gpu_ctx_factory):
         gpu_ctx_factory(rt.Scene.reference(6)).render(16, 16, 1, variant=0)
 
 
+def test_sorted_and_unsorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
+    """The workgroup-level reordering only changes which lane runs which path: same bits, same segment count,
+    on ragged tiles, tiny images (fewer paths than one workgroup), depth limits and sample offsets."""
+    sc = rt.Scene.reference(5, build_seed=1)
+    ctx = gpu_ctx_factory(sc)
+    for (W, H, spp, tile, kw) in ((96, 96, 16, None, {}), (200, 200, 3, (0, 0, 37, 23), {}), (200, 200, 40, (5, 7, 100, 9), {}),
+                                  (2, 2, 5, None, {}), (64, 64, 8, None, dict(max_depth=2)), (64, 64, 8, None, dict(sample_offset=100, out_sum=True)),
+                                  (600, 600, 20, None, dict(chunk=7))):
+        a, sa = ctx.render(W, H, spp, tile=tile, unsorted=True, **kw)
+        b, sb = ctx.render(W, H, spp, tile=tile, **kw)
+        assert sa["sorted"] == 0 and sb["sorted"] == 1
+        assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (W, H, spp, tile, kw)
+
+
 def test_gpu_matches_committed_golden_frames(rt, gpu_ctx_factory):
     meta = json.load(open(os.path.join(HERE, "golden", "oracle_frames.json")))
     gold = np.load(os.path.join(HERE, "golden", "oracle_frames.npz"))
