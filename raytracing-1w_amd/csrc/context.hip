@@ -192,7 +192,7 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVE
  * and are summed in order), so the framebuffer is bit-identical to the unsorted kernel's. */
 #define RT_XCH_QW 26 /* qwords of per-path state exchanged */
 template <class Cfg>
-__global__ __launch_bounds__(RT_BLOCK, 3) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+__global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? 3 : 2) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                                       unsigned long long* __restrict__ counters) {
     constexpr int NW = RT_BLOCK / 64;
     __shared__ unsigned long long xch[RT_XCH_QW * RT_BLOCK];
@@ -400,8 +400,9 @@ struct rt1w_context {
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
 static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV0>, rt_render_kernel<RtCfgV1>,
                                                          rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>};
-/* the reordering kernel exists for the variants where it pays (measured): V0 */
-static render_kernel_t const g_kernels_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted<RtCfgV0>, nullptr, nullptr, nullptr};
+/* the reordering kernel exists for the variants where it pays (measured): the sweep variants */
+static render_kernel_t const g_kernels_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted<RtCfgV0>, rt_render_kernel_sorted<RtCfgV1>,
+                                                                nullptr, nullptr}; /* stack variants: measured 0.55x (LDS for stack + exchange halves occupancy) */
 
 namespace {
 

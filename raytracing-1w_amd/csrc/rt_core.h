@@ -247,18 +247,20 @@ RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bo
     h.t = t; h.u = 0.0; h.v = 0.0; h.mat = nd.mat;
     h.p = rt_at(r.o, r.d, t);
     RtV3 on;
-    if (nd.kind == RT_SPHERE || nd.kind == RT_MSPHERE) {
-        if (!Cfg::msphere || nd.kind == RT_SPHERE) on = (h.p - rt_v3(nd.d[0], nd.d[1], nd.d[2])) / nd.d[3];
+    const uint32_t kind = nd.kind & RT_KIND_MASK;
+    const bool flipped = (nd.kind & RT_LEAF_FLIPPED) != 0u;
+    if (kind == RT_SPHERE || kind == RT_MSPHERE) {
+        if (!Cfg::msphere || kind == RT_SPHERE) on = (h.p - rt_v3(nd.d[0], nd.d[1], nd.d[2])) / nd.d[3];
         else on = (h.p - rt_msphere_center(nd, time)) / nd.d[8];
         if (Cfg::tex && want_uv) rt_sphere_uv(on, h.u, h.v);
-    } else if (Cfg::media && nd.kind == RT_MEDIUM) {
+    } else if (Cfg::media && kind == RT_MEDIUM) {
         h.n = rt_v3(1.0, 0.0, 0.0);
         h.front = true;
         return;
     } else {
         double b, c;
-        if (nd.kind == RT_XY) { on = rt_v3(0.0, 0.0, 1.0); b = r.o.x + t * r.d.x; c = r.o.y + t * r.d.y; }
-        else if (nd.kind == RT_XZ) { on = rt_v3(0.0, 1.0, 0.0); b = r.o.x + t * r.d.x; c = r.o.z + t * r.d.z; }
+        if (kind == RT_XY) { on = rt_v3(0.0, 0.0, 1.0); b = r.o.x + t * r.d.x; c = r.o.y + t * r.d.y; }
+        else if (kind == RT_XZ) { on = rt_v3(0.0, 1.0, 0.0); b = r.o.x + t * r.d.x; c = r.o.z + t * r.d.z; }
         else { on = rt_v3(1.0, 0.0, 0.0); b = r.o.y + t * r.d.y; c = r.o.z + t * r.d.z; }
         if (Cfg::tex && want_uv) {
             h.u = (b - nd.d[0]) / (nd.d[1] - nd.d[0]);
@@ -268,7 +270,7 @@ RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bo
     /* HitRecord::new hittable.rs:30-35 */
     bool front = rt_dot(r.d, on) < 0.0;
     h.n = front ? on : -on;
-    h.front = front;
+    h.front = flipped ? !front : front; /* FlipFace::hit hittable.rs:288-291 flips the flag only */
 }
 
 /* Full hit record of the winning leaf: leaf record in its own space, then the
@@ -295,23 +297,22 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
     rt_scope_out(nodes[c.s0], r1, h);
 }
 
-/* static sphere and the three rects, from the hot half of the record (same operations as rt_prim_t) */
+/* static sphere and the three rects, from the hot half of the record (same operations as
+ * rt_prim_t).  `kind` is wave-uniform in the sweep, so the axis choice is a scalar branch. */
+RT_HD bool rt_rect_hot_t(const RtNodeHot& nd, double oa, double da, double ob, double db, double oc, double dc,
+                         double t_min, double t_max, double& t_out) {
+    double t = (nd.d[4] - oa) / da;
+    if (t < t_min || t > t_max) return false;
+    double b = ob + t * db;
+    double c = oc + t * dc;
+    if (b < nd.d[0] || b > nd.d[1] || c < nd.d[2] || c > nd.d[3]) return false;
+    t_out = t;
+    return true;
+}
 RT_HD bool rt_prim_hot_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d, double t_min, double t_max, double& t_out) {
-    if (kind >= RT_XY) {
-        double oa = kind == RT_XY ? o.z : (kind == RT_XZ ? o.y : o.x);
-        double da = kind == RT_XY ? d.z : (kind == RT_XZ ? d.y : d.x);
-        double ob = kind == RT_YZ ? o.y : o.x;
-        double db = kind == RT_YZ ? d.y : d.x;
-        double oc = kind == RT_XY ? o.y : o.z;
-        double dc = kind == RT_XY ? d.y : d.z;
-        double t = (nd.d[4] - oa) / da;
-        if (t < t_min || t > t_max) return false;
-        double b = ob + t * db;
-        double c = oc + t * dc;
-        if (b < nd.d[0] || b > nd.d[1] || c < nd.d[2] || c > nd.d[3]) return false;
-        t_out = t;
-        return true;
-    }
+    if (kind == RT_XY) return rt_rect_hot_t(nd, o.z, d.z, o.x, d.x, o.y, d.y, t_min, t_max, t_out);
+    if (kind == RT_XZ) return rt_rect_hot_t(nd, o.y, d.y, o.x, d.x, o.z, d.z, t_min, t_max, t_out);
+    if (kind == RT_YZ) return rt_rect_hot_t(nd, o.x, d.x, o.y, d.y, o.z, d.z, t_min, t_max, t_out);
     return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t_out);
 }
 
@@ -374,7 +375,7 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
             continue;
         }
         const RtNode& nd = nodes[e];
-        uint32_t kind = nd.kind;
+        uint32_t kind = nd.kind & RT_KIND_MASK;
         if (kind <= RT_BVH1) {
             bool hit;
             if (RT_WAVE_ANY(rt_isnan(t_min) || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, cur.o, inv, t_min, best_t);
@@ -451,7 +452,7 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
         RT_STAMP(9);
         bool active = (cur == n);
         if (!RT_WAVE_ANY(active)) { RT_STAMP(10); continue; }
-        const uint32_t kind = nd.kind;
+        const uint32_t kind = nd.kind & RT_KIND_MASK;
         if (active) {
             RT_STAT_VISIT(kind);
             if (kind <= RT_BVH1) {

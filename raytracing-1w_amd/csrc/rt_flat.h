@@ -29,8 +29,12 @@ enum {
     RT_ROTATE_Y = 8,  /* src/hittable.rs:54-59   d[0]=sin d[1]=cos a=child b=parent scope */
     RT_FLIP = 9,      /* src/hittable.rs:61      a=child b=parent scope */
     RT_MEDIUM = 10,   /* src/constant_medium.rs:15-19 d[0]=neg_inv_density mat=phase fn a=boundary root */
-    RT_DEFAULT = 11   /* lights table only: a hittable without pdf_value/random overrides
+    RT_DEFAULT = 11,  /* lights table only: a hittable without pdf_value/random overrides
                          (src/hittable.rs:66-71 defaults) */
+    RT_KIND_MASK = 0xFF,
+    RT_LEAF_FLIPPED = 0x100 /* leaf wrapped directly by FlipFace (hittable.rs:286-292): the flattener folds the
+                               wrapper into this flag; the flip is applied right after the leaf's own record,
+                               i.e. exactly where the innermost wrapper's fix-up would run */
 };
 
 /* Layout: the fields a traversal step reads (kind, skip and the first 7 doubles: a whole

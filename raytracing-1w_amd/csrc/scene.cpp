@@ -173,6 +173,14 @@ struct Flattener {
                 return idx;
             }
             case RT_TRANSLATE: case RT_ROTATE_Y: case RT_FLIP: {
+                if (h.kind == RT_FLIP) { /* FlipFace(leaf): fold into the leaf record */
+                    uint32_t ck = s.hittables[h.child].kind;
+                    if (ck == RT_SPHERE || ck == RT_MSPHERE || ck == RT_XY || ck == RT_XZ || ck == RT_YZ) {
+                        uint32_t idx = emit(h.child, parent_scope, scope_depth, in_boundary, need);
+                        if (ok) out[idx].kind |= RT_LEAF_FLIPPED;
+                        return idx;
+                    }
+                }
                 if (scope_depth + 1 > RT_MAX_SCOPE_DEPTH) {
                     fail(RT1W_ERR_UNSUPPORTED, "more than RT_MAX_SCOPE_DEPTH nested Translate/RotateY/FlipFace wrappers");
                     return RT_NONE;
@@ -568,7 +576,7 @@ int rt1w_scene_commit(rt1w_scene* s) {
         std::vector<RtNode>& N = s->flat_nodes;
         struct R { static uint32_t fill(std::vector<RtNode>& N, uint32_t i) {
             uint32_t end = i + 1;
-            uint32_t k = N[i].kind;
+            uint32_t k = N[i].kind & RT_KIND_MASK;
             if (k == RT_BVH2) { end = fill(N, N[i].a); end = fill(N, N[i].b); }
             else if (k == RT_BVH1 || k == RT_TRANSLATE || k == RT_ROTATE_Y || k == RT_FLIP || k == RT_MEDIUM) end = fill(N, N[i].a);
             N[i].skip = end;
@@ -576,7 +584,7 @@ int rt1w_scene_commit(rt1w_scene* s) {
         } };
         R::fill(N, root);
         for (uint32_t i = 0; i < N.size(); ++i) {
-            uint32_t k = N[i].kind;
+            uint32_t k = N[i].kind & RT_KIND_MASK;
             if (k == RT_BVH2 && (N[i].a != i + 1 || N[i].b != N[N[i].a].skip)) { set_error("internal: nodes not in pre-order"); return RT1W_ERR_INVALID; }
             if ((k == RT_BVH1 || (k >= RT_TRANSLATE && k <= RT_MEDIUM)) && N[i].a != i + 1) { set_error("internal: nodes not in pre-order"); return RT1W_ERR_INVALID; }
         }
@@ -588,7 +596,7 @@ int rt1w_scene_commit(rt1w_scene* s) {
     s->has_tex = false;
     for (const RtTexture& t : s->textures) if (t.kind != RT_TEX_SOLID) s->has_tex = true;
     s->has_msphere = false;
-    for (const RtNode& n : s->flat_nodes) if (n.kind == RT_MSPHERE) s->has_msphere = true;
+    for (const RtNode& n : s->flat_nodes) if ((n.kind & RT_KIND_MASK) == RT_MSPHERE) s->has_msphere = true;
     if (s->stack_need > RT_STACK_CAP) {
         set_error("scene needs a deeper traversal stack than RT_STACK_CAP");
         s->flat_nodes.clear();

@@ -76,7 +76,7 @@ def test_unsupported_graph_shapes_are_reported(rt):
     s = rt.Scene(build_seed=1)
     m = s.lambertian(s.solid_color((0.5, 0.5, 0.5)))
     h = s.sphere((0, 0, 0), 1.0, m)
-    for _ in range(4):                               # 4 nested wrappers > RT_MAX_SCOPE_DEPTH
+    for _ in range(5):                               # innermost FlipFace folds into the leaf; 4 more wrappers > RT_MAX_SCOPE_DEPTH
         h = s.flip_face(h)
     s.set_world(s.bvh_node([h]))
     s.set_camera((0, 0, -5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 0.0, 1.0)
@@ -100,11 +100,13 @@ def test_flattened_cornell_structure(rt):
     sc = rt.Scene.reference(5, build_seed=1)
     info = sc.info()
     nodes = sc.flat(0).view(np.uint32).reshape(-1, 24)
-    kinds = nodes[:, 0]
-    assert info["n_nodes"] == 30 and info["n_lights"] == 2 and info["has_media"] == 0
+    kinds = nodes[:, 0] & 0xFF
+    flipped = (nodes[:, 0] & 0x100) != 0
+    assert info["n_nodes"] == 29 and info["n_lights"] == 2 and info["has_media"] == 0
     assert (kinds <= 1).sum() == 14                  # BVH nodes: 7 top + 7 in the box
     assert ((kinds >= 2) & (kinds <= 6)).sum() == 13 # 5 walls + light + 6 box sides + sphere
-    assert sorted(kinds[kinds >= 7]) == [7, 8, 9]    # Translate, RotateY, FlipFace
+    assert sorted(kinds[kinds >= 7]) == [7, 8]       # Translate, RotateY; FlipFace(light rect) is folded into the leaf
+    assert flipped.sum() == 1 and kinds[flipped][0] == 5
     assert sc.defaults == (600, 600, 100)            # main.rs:868-870
     # camera block: origin = look_from
     cam = sc.flat(6).view(np.float64)

@@ -19,3 +19,17 @@ for uns in (True, False):
         g, s = ctx.render(600, 600, 200, unsorted=uns)
         best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
     print("unsorted" if uns else "sorted  ", "Mpaths/s", round(best, 1), "grid", s["grid"], flush=True)
+
+for arm, (W, H, spp) in {6: (600, 600, 50), 0: (600, 400, 50), 7: (400, 400, 32)}.items():
+    sc2 = rt.Scene.reference(arm, aspect_ratio=1.5 if arm == 0 else None)
+    c2 = rt.Context(sc2, 0)
+    a, sa = c2.render(W, H, 4, unsorted=True)
+    b, sb = c2.render(W, H, 4)
+    res = {}
+    for uns in (True, False):
+        best = 0
+        for _ in range(2):
+            g, s = c2.render(W, H, spp, unsorted=uns)
+            best = max(best, s["paths"] / s["kernel_ms"] / 1e3)
+        res[uns] = round(best, 1)
+    print("arm", arm, "variant", sb["variant"], "bit-exact", np.array_equal(a, b, equal_nan=True), "unsorted", res[True], "sorted", res[False], flush=True)
