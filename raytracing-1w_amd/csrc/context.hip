@@ -191,22 +191,25 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVE
  * (a path is a pure function of its state; a pixel chunk's samples still run one after the other
  * and are summed in order), so the framebuffer is bit-identical to the unsorted kernel's. */
 #define RT_XCH_QW 26 /* qwords of per-path state exchanged */
+#ifndef RT_SORT_BLOCK
+#define RT_SORT_BLOCK 256 /* paths sorted together = workgroup size of the reordering kernel */
+#endif
 template <class Cfg>
-__global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? 3 : 2) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+__global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                                       unsigned long long* __restrict__ counters) {
-    constexpr int NW = RT_BLOCK / 64;
-    __shared__ unsigned long long xch[RT_XCH_QW * RT_BLOCK];
+    constexpr int NW = RT_SORT_BLOCK / 64;
+    static_assert(Cfg::sweep, "the reordering kernel is built for the stackless variants");
+    __shared__ unsigned long long xch[RT_XCH_QW * RT_SORT_BLOCK];
     __shared__ uint32_t cnt[NW][RT_N_CLS];
-    __shared__ uint32_t stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
     LdsStack stk;
-    stk.base = stack_mem + threadIdx.x;
+    stk.base = nullptr;
     stk.sp = 0;
     RtGlobalNodes ns{sc.nodes};
 
     const unsigned long long n_items = rt_item_count(f);
     const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long item = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    unsigned long long item = (unsigned long long)blockIdx.x * RT_SORT_BLOCK + threadIdx.x;
     bool fresh = true, have = false, retired = false;
     uint32_t px = 0, py = 0, chunk = 0, s = 0;
     RtV3 sum = rt_v3(0.0, 0.0, 0.0);
@@ -276,10 +279,10 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? 3 : 2) void r
                 if (c == RT_CLS_IDLE) idle_total += v;
             }
         }
-        if (idle_total == RT_BLOCK) break; /* every path of the workgroup is done (uniform) */
+        if (idle_total == RT_SORT_BLOCK) break; /* every path of the workgroup is done (uniform) */
         {
             unsigned long long* q = xch + dest;
-#define RT_PUT64(x) do { *q = (x); q += RT_BLOCK; } while (0)
+#define RT_PUT64(x) do { *q = (x); q += RT_SORT_BLOCK; } while (0)
 #define RT_PUTD(x) RT_PUT64(rt_d2u(x))
 #define RT_PUT2(a, b) RT_PUT64(((unsigned long long)(b) << 32) | (unsigned long long)(uint32_t)(a))
             RT_PUTD(path.ray.o.x); RT_PUTD(path.ray.o.y); RT_PUTD(path.ray.o.z);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? 3 : 2) void r
         {
             const unsigned long long* q = xch + threadIdx.x;
             unsigned long long v_;
-#define RT_GET64() (v_ = *q, q += RT_BLOCK, v_)
+#define RT_GET64() (v_ = *q, q += RT_SORT_BLOCK, v_)
 #define RT_GETD(x) (x) = rt_u2d(RT_GET64())
 #define RT_GET2(a, b) do { unsigned long long t_ = RT_GET64(); (a) = (uint32_t)t_; (b) = (uint32_t)(t_ >> 32); } while (0)
             RT_GETD(path.ray.o.x); RT_GETD(path.ray.o.y); RT_GETD(path.ray.o.z);
@@ -451,11 +454,12 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
     }
     const bool sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     const int grid = sorted ? c->grid_sorted[variant] : c->grid[variant];
-    unsigned long long init[2] = {(unsigned long long)grid * RT_BLOCK, 0ull};
+    const int block = sorted ? RT_SORT_BLOCK : RT_BLOCK;
+    unsigned long long init[2] = {(unsigned long long)grid * block, 0ull};
     if (!hip_ok(hipMemcpyAsync(c->d_counters, init, sizeof init, hipMemcpyHostToDevice, c->stream), "counter init")) return RT1W_ERR_DEVICE;
     if (!hip_ok(hipStreamSynchronize(c->stream), "counter init sync")) return RT1W_ERR_DEVICE;
     (void)hipEventRecord(c->ev0, c->stream);
-    hipLaunchKernelGGL(sorted ? g_kernels_sorted[variant] : g_kernels[variant], dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->view, f,
+    hipLaunchKernelGGL(sorted ? g_kernels_sorted[variant] : g_kernels[variant], dim3(grid), dim3(block), 0, c->stream, c->view, f,
                        c->d_partial, c->d_counters);
     {
         unsigned int rb = 256;
@@ -475,7 +479,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
         stats->segments = cnt[1];
         stats->kernel_ms = ms;
         stats->chunk = f.chunk; stats->n_chunks = f.n_chunks;
-        stats->grid = (uint32_t)grid; stats->block = RT_BLOCK;
+        stats->grid = (uint32_t)grid; stats->block = (uint32_t)block;
         stats->variant = (uint32_t)variant; stats->sorted = sorted ? 1u : 0u;
     }
     return RT1W_OK;
@@ -546,7 +550,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
         c->grid[v] = prop.multiProcessorCount * per_cu;
         if (g_kernels_sorted[v]) {
             per_cu = 0;
-            if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_sorted[v], RT_BLOCK, 0), "occupancy query")) {
+            if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_sorted[v], RT_SORT_BLOCK, 0), "occupancy query")) {
                 rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
             }
             if (per_cu < 1) per_cu = 1;
