@@ -50,9 +50,6 @@ __device__ __forceinline__ void rt_stamp_fn(int k) {
 #include "scene.h"
 
 #define RT_BLOCK 256
-#ifndef RT_LANE_NODES
-#define RT_LANE_NODES 0 /* experiment (measured slower: +14 VGPRs and extra VALU): hot node words in registers, v_readlane fetch; only valid for scenes of <= 64 nodes */
-#endif
 
 namespace {
 
@@ -61,31 +58,6 @@ struct LdsStack {
     int sp;
     __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
     __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
-};
-
-/* Scene resident in the register file: lane i keeps the hot words (kind, skip, 6 doubles) of
- * node i; v_readlane with the wave-uniform node index fetches them.  <= 64 nodes. */
-struct LaneNodes {
-    uint32_t w[14];
-    __device__ __forceinline__ void load(const RtNode* nodes, uint32_t n_nodes) {
-        uint32_t i = threadIdx.x & 63u;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + (i < n_nodes ? i : n_nodes - 1u));
-#pragma unroll
-        for (int k = 0; k < 14; ++k) w[k] = src[k];
-    }
-    __device__ __forceinline__ RtNodeHot hot(uint32_t n) const {
-        RtNodeHot h;
-        h.kind = (uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)n);
-        h.skip = (uint32_t)__builtin_amdgcn_readlane((int)w[1], (int)n);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w[2 + 2 * k], (int)n);
-            uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)w[3 + 2 * k], (int)n);
-            h.d[k] = rt_u2d(((uint64_t)hi << 32) | lo);
-        }
-        h.d[6] = 0.0;
-        return h;
-    }
 };
 
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
@@ -104,12 +76,7 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVE
     LdsStack stk;
     stk.base = stack_mem + threadIdx.x;
     stk.sp = 0;
-#if RT_LANE_NODES
-    typename std::conditional<Cfg::sweep, LaneNodes, RtGlobalNodes>::type ns;
-    if constexpr (Cfg::sweep) ns.load(sc.nodes, sc.n_nodes); else ns.p = sc.nodes;
-#else
     RtGlobalNodes ns{sc.nodes};
-#endif
 
 #ifdef RT_STAMPS
     if ((threadIdx.x & 63) == 0) {

@@ -21,7 +21,7 @@ enum {
     RT_BVH2 = 0,      /* BVHChild::Two   src/bvh.rs:11,38-47   d[0..5]=aabb min,max  a=left b=right */
     RT_BVH1 = 1,      /* BVHChild::One   src/bvh.rs:10,37      d[0..5]=aabb          a=child */
     RT_SPHERE = 2,    /* src/sphere.rs:16-20      d[0..2]=center d[3]=radius  mat */
-    RT_MSPHERE = 3,   /* src/moving_sphere.rs:13-20 d[0..2]=c0 d[3..5]=c1 d[6]=t0 d[7]=t1 d[8]=radius mat */
+    RT_MSPHERE = 3,   /* src/moving_sphere.rs:13-20 d[0..2]=c0 d[3..5]=c1 e[0]=t0 e[1]=t1 e[2]=radius mat */
     RT_XY = 4,        /* src/aarect.rs:15-22  d[0..4]=x0,x1,y0,y1,k mat */
     RT_XZ = 5,        /* src/aarect.rs:25-32  d[0..4]=x0,x1,z0,z1,k mat */
     RT_YZ = 6,        /* src/aarect.rs:35-42  d[0..4]=y0,y1,z0,z1,k mat */
@@ -37,23 +37,27 @@ enum {
                                i.e. exactly where the innermost wrapper's fix-up would run */
 };
 
-/* Layout: the fields a traversal step reads (kind, skip and the first 7 doubles: a whole
- * AABB, rect, sphere or wrapper) are the first 64 bytes -- one s_load_dwordx16 when the
- * index is wave-uniform (sweep), four dwordx4 when it is per-lane (stack). */
+/* Layout: everything a traversal step reads (kind, skip, a whole AABB / rect / sphere / wrapper,
+ * the right child and the material) is the first 64 bytes -- one s_load_dwordx16 when the index is
+ * wave-uniform (sweep), four dwordx4 when it is per-lane (stack).  The left child of a BVH node, the
+ * child of a wrapper and the boundary of a medium are always the next node (pre-order). */
 struct RtNode {
     uint32_t kind;
     uint32_t skip; /* nodes are stored in depth-first pre-order: [index, skip) is this node's subtree */
-    double d[9];
+    double d[6];
+    uint32_t b;    /* BVH2: right child; wrapper: parent wrapper (RT_NONE at top level) */
     uint32_t mat;
-    uint32_t a;
-    uint32_t b;
+    double e[3];   /* MovingSphere only: time0, time1, radius */
+    uint32_t a;    /* == index + 1 for BVH / wrapper / medium nodes */
     uint32_t pad;
 }; /* 96 bytes */
 /* the first 64 bytes of an RtNode */
 struct RtNodeHot {
     uint32_t kind;
     uint32_t skip;
-    double d[7];
+    double d[6];
+    uint32_t b;
+    uint32_t mat;
 };
 
 /* material kinds: every `impl Material` */

@@ -152,6 +152,7 @@ struct Flattener {
             case RT_SPHERE: case RT_MSPHERE: case RT_XY: case RT_XZ: case RT_YZ: {
                 RtNode n = blank(h.kind);
                 std::memcpy(n.d, h.d, sizeof n.d);
+                n.e[0] = h.d[6]; n.e[1] = h.d[7]; n.e[2] = h.d[8];
                 n.mat = (uint32_t)h.mat;
                 out.push_back(n);
                 return (uint32_t)out.size() - 1;

@@ -1,6 +1,7 @@
 """First GPU contact: GPU render vs CPU build of the same core (bit-exact expected), then a timing."""
 import sys, time, numpy as np
-sys.path.insert(0, 'tests')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import orc
 rt = orc.rt()
 print(rt.version(), 'devices', rt.device_count(), flush=True)

@@ -1,6 +1,7 @@
 """Quick GPU throughput check (not the contract bench): Cornell + the other scenes, kernel time only."""
 import sys
-sys.path.insert(0, 'tests')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import orc
 rt = orc.rt()
 which = sys.argv[1:] or ['5']

@@ -1,7 +1,8 @@
 """A/B: workgroup-sorted kernel vs unsorted (bit-exact expected), Cornell."""
 import sys
 import numpy as np
-sys.path.insert(0, 'tests')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import orc
 rt = orc.rt()
 sc = rt.Scene.reference(5)

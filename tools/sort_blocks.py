@@ -1,7 +1,8 @@
 """Compare sort-domain sizes; first a small bit-exactness check against the unsorted kernel (guards against a bad build)."""
 import sys
 import numpy as np
-sys.path.insert(0, 'tests')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import orc
 rt = orc.rt()
 sc = rt.Scene.reference(5)

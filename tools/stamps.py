@@ -1,7 +1,8 @@
 """Per-phase cycle shares of the render kernel (diagnostic build librt1w_stamps.so)."""
 import os, sys
 os.environ["RT1W_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracing-1w_amd", "librt1w_stamps.so")
-sys.path.insert(0, 'tests')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import orc
 rt = orc.rt()
 names = ["loop/other", "regen", "traverse(rest)", "hit record", "shade lambert", "shade other", "bookkeeping", "-", "sweep setup", "sweep pop+hdr", "sweep idle step", "sweep bvh step", "sweep prim step", "sweep scope step", "-", "-"]
