@@ -193,6 +193,10 @@ int64_t rt1w_format_ppm(const double* means, uint32_t width, uint32_t height, ch
  * 7 first gen_f64 of stream (pixel=i, sample=(uint32)a_bits), 8 gen_range(-1,1) of same.
  * Used by the GPU tests to prove host/device bit equality. */
 int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, double* out, uint64_t n);
+/* AABB::hit (src/aabb.rs:13-32) ON THE DEVICE for n cases, in[i] = {min[3], max[3], origin[3], direction[3], t_min, t_max}:
+ * `out_literal` from the compare/select form, `out_fast` from the max/min-instruction form the kernels use when no
+ * bound is NaN.  Tests compare both with the host's literal form. */
+int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* out_fast, uint64_t n);
 /* per-phase wave-cycle totals of the render kernel since the last reset.  Only the diagnostic build
  * (make stamps -> librt1w_stamps.so, -DRT_STAMPS) fills them (returns 1); the shipped library executes no
  * stamp and returns 0 with zeros.  Buckets: see context.hip. */

@@ -116,6 +116,7 @@ _sig("rt1w_resolve", C.c_int, _P, C.c_uint64, C.c_uint32, _P)
 _sig("rt1w_quantize", C.c_int, _P, C.c_uint64, _P)
 _sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
 _sig("rt1w_debug_eval", C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64)
+_sig("rt1w_debug_aabb", C.c_int, _P, _P, _P, _P, C.c_uint64)
 _sig("rt1w_debug_stamps", C.c_int, _P, C.POINTER(C.c_uint64 * 16), C.c_int)
 
 
@@ -316,6 +317,14 @@ class Context:
         st = Stats()
         _ck(_lib.rt1w_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.byref(st)))
         return {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def debug_aabb(self, cases):
+        """cases[n, 14] = min3, max3, origin3, direction3, t_min, t_max -> (literal[n], fast[n]) from the device."""
+        a = np.ascontiguousarray(cases, dtype=np.float64).reshape(-1, 14)
+        lit = np.empty(a.shape[0], dtype=np.int32)
+        fast = np.empty(a.shape[0], dtype=np.int32)
+        _ck(_lib.rt1w_debug_aabb(self._h, a.ctypes.data_as(_P), lit.ctypes.data_as(_P), fast.ctypes.data_as(_P), a.shape[0]))
+        return lit, fast
 
     def debug_stamps(self, reset=True):
         out = (C.c_uint64 * 16)()

@@ -323,6 +323,17 @@ __global__ void rt_resolve_kernel(const double* __restrict__ partial, double* __
     out[p * 3 + 0] = total.x; out[p * 3 + 1] = total.y; out[p * 3 + 2] = total.z;
 }
 
+/* AABB slab test on the device, both forms, for tests: in[i] = {bb[6], o[3], d[3], t_min, t_max} */
+__global__ void rt_debug_aabb_kernel(const double* in, int* out_literal, int* out_fast, unsigned long long n) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = in + i * 14;
+    RtV3 o = rt_v3(p[6], p[7], p[8]);
+    RtV3 inv = rt_inv3(rt_v3(p[9], p[10], p[11]));
+    out_literal[i] = rt_aabb_hit(p, o, inv, p[12], p[13]) ? 1 : 0;
+    out_fast[i] = rt_aabb_hit_fast(p, o, inv, p[12], p[13]) ? 1 : 0;
+}
+
 __global__ void rt_debug_eval_kernel(int fn, const double* a, const double* b, double* out, unsigned long long n) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -573,6 +584,26 @@ int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, r
     if (!hip_ok(hipMemcpy(out_rgb, c->d_out, bytes, hipMemcpyDeviceToHost), "framebuffer copy")) return RT1W_ERR_DEVICE;
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT1W_OK;
+}
+
+int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* out_fast, uint64_t n) {
+    if (!c || !in || !out_literal || !out_fast) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (n == 0) return RT1W_OK;
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    double* din = nullptr; int *d0 = nullptr, *d1 = nullptr;
+    int rc = RT1W_OK;
+    if (!hip_ok(hipMalloc((void**)&din, n * 14 * sizeof(double)), "hipMalloc") || !hip_ok(hipMalloc((void**)&d0, n * sizeof(int)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void**)&d1, n * sizeof(int)), "hipMalloc")) rc = RT1W_ERR_NOMEM;
+    if (rc == RT1W_OK) {
+        (void)hipMemcpy(din, in, n * 14 * sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(rt_debug_aabb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, din, d0, d1, (unsigned long long)n);
+        if (!hip_ok(hipStreamSynchronize(c->stream), "debug kernel")) rc = RT1W_ERR_DEVICE;
+        else { (void)hipMemcpy(out_literal, d0, n * sizeof(int), hipMemcpyDeviceToHost); (void)hipMemcpy(out_fast, d1, n * sizeof(int), hipMemcpyDeviceToHost); }
+    }
+    if (din) (void)hipFree(din);
+    if (d0) (void)hipFree(d0);
+    if (d1) (void)hipFree(d1);
+    return rc;
 }
 
 int rt1w_debug_stamps(rt1w_context* c, uint64_t out[16], int reset) {

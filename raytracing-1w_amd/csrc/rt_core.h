@@ -99,14 +99,23 @@ RT_HD bool rt_aabb_hit(const double* bb, RtV3 o, RtV3 inv, double t_min, double 
  * is NaN and so does maxNum; equal values or zeros of either sign give the same comparisons
  * afterwards (t_min, t_max are not outputs).  Callers take the literal form when a NaN bound
  * is present (a NaN root was accepted earlier -- reference behaviour, reproduced). */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_ASM_MINMAX)
+/* the bare instructions: __builtin_fmax/fmin make the compiler canonicalise each operand first
+ * (a v_max_f64 x,x,x apiece); every operand here is an arithmetic result or a previous max/min */
+RT_HD double rt_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_HD double rt_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+RT_HD double rt_vmax(double a, double b) { return __builtin_fmax(a, b); }
+RT_HD double rt_vmin(double a, double b) { return __builtin_fmin(a, b); }
+#endif
 RT_HD bool rt_aabb_hit_fast(const double* bb, RtV3 o, RtV3 inv, double t_min, double t_max) {
 #define RT_SLAB(minv, maxv, ov, iv)                      \
     {                                                    \
         double t0 = ((minv) - (ov)) * (iv);              \
         double t1 = ((maxv) - (ov)) * (iv);              \
         if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
-        t_min = __builtin_fmax(t0, t_min);               \
-        t_max = __builtin_fmin(t1, t_max);               \
+        t_min = rt_vmax(t0, t_min);                      \
+        t_max = rt_vmin(t1, t_max);                      \
         if (t_max <= t_min) return false;                \
     }
     RT_SLAB(bb[0], bb[3], o.x, inv.x)

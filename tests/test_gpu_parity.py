@@ -50,6 +50,41 @@ def test_numerical_contract_bit_identical_on_device(rt, gpu_ctx_factory):
         assert np.array_equal(np.isnan(host), np.isnan(dev)), f"fn {fn}"
 
 
+def test_device_aabb_forms_match_host_literal(rt, gpu_ctx_factory):
+    """The slab test as the kernels run it (max/min instructions, taken when no bound is NaN) and the literal
+    compare/select form, both on the device, against the oracle's AABB::hit on the host -- on random boxes and rays
+    plus the nasty ones: zero / negative-zero / infinite / NaN direction and origin components, origins on a slab
+    plane (0 * inf = NaN), empty and inverted intervals, infinite bounds."""
+    import ctypes as C
+    ctx = gpu_ctx_factory(rt.Scene.reference(5))
+    rng = np.random.default_rng(7)
+    n = 200_000
+    c = np.empty((n, 14))
+    lo = rng.uniform(-10, 10, (n, 3)); ext = rng.uniform(0, 8, (n, 3))
+    c[:, 0:3] = lo; c[:, 3:6] = lo + ext
+    c[:, 6:9] = rng.uniform(-15, 15, (n, 3))
+    c[:, 9:12] = rng.normal(size=(n, 3))
+    aim = rng.random(n) < 0.6                                                # most rays are aimed at their box
+    c[aim, 9:12] = (lo + ext * rng.random((n, 3)) - c[:, 6:9])[aim] * rng.uniform(0.05, 3.0, (n, 1))[aim]
+    c[:, 12] = rng.choice([0.001, -np.inf, 0.0, 1.0], n)
+    c[:, 13] = rng.choice([np.inf, 5.0, 50.0, 0.5], n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-300, 1e300])
+    k = n // 2
+    idx = rng.integers(0, 3, k)
+    c[np.arange(k), 9 + idx] = rng.choice(special, k)                       # special direction components
+    k2 = n // 4
+    ax = rng.integers(0, 3, k2)
+    c[np.arange(k2), 6 + ax] = c[np.arange(k2), 0 + ax]                     # origin exactly on a slab plane
+    c[np.arange(0, n, 97), 6 + rng.integers(0, 3)] = np.nan                 # NaN origin component
+    lit, fast = ctx.debug_aabb(c)
+    host = np.array([orc.A.orc_aabb_hit(r[0:3].ctypes.data_as(C.c_void_p), r[3:6].ctypes.data_as(C.c_void_p),
+                                        r[6:9].ctypes.data_as(C.c_void_p), r[9:12].ctypes.data_as(C.c_void_p), r[12], r[13])
+                     for r in np.ascontiguousarray(c[:20000])], dtype=np.int32)
+    assert np.array_equal(lit[:20000], host)
+    assert np.array_equal(lit, fast)          # t_min / t_max are never NaN here: the regime in which the kernels use `fast`
+    assert 0.1 < lit.mean() < 0.9
+
+
 @pytest.mark.parametrize("arm", sorted(SMALL))
 def test_gpu_bit_exact_vs_core_and_close_to_literal(rt, gpu_ctx_factory, arm):
     W, H, spp = SMALL[arm]
