@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp", type=int, default=SPP, help="debug only; the contract workload is 1000")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="rehearsal only (1-GPU box): every rank uses this device instead of LOCAL_RANK")
     a = ap.parse_args()
 
     import torch
@@ -69,6 +71,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: barrier + max(time)
 
+    if a.all_ranks_on_device is not None:
+        local_rank = a.all_ranks_on_device
     assert torch.cuda.is_available() and rt.device_count() > local_rank, "bench.py needs the GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     scene = rt.Scene.reference(5, build_seed=1)
