@@ -129,11 +129,11 @@ def main():
                        "width": W, "height": H, "spp_per_gpu": spp, "max_depth": DEPTH,
                        "paths_per_step": paths_per_step, "segments_per_path": round(segs / (W * H * spp), 4),
                        "chunk": st["chunk"], "n_chunks": st["n_chunks"], "grid": st["grid"], "block": st["block"],
-                       "kernel_variant": st["variant"], "workgroup_path_sort": bool(st.get("sorted")),
+                       "kernel_variant": st["variant"], "workgroup_path_sort": bool(st.get("sorted", 0) & 1),
                        "parallelism": f"sample-range x{world}, host gather, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "rt_render_kernel_sorted<V%d>" % st["variant"] if st.get("sorted") else "rt_render_kernel<V%d>" % st["variant"],
+                         "kernel": "rt_render_kernel_sorted<V%d>" % st["variant"] if (st.get("sorted", 0) & 1) else "rt_render_kernel<V%d>" % st["variant"],
                          "kernel_ms": round(avg_ms, 3),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "compute-bound f64 kernel: ray state stays in VGPRs, so real HBM traffic is far "

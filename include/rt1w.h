@@ -139,6 +139,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out);
 void rt1w_context_destroy(rt1w_context* c);
 
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
+#define RT1W_NO_LDS_NODES 4u /* tests/ablation: stack variants fetch nodes from memory even when the hot halves would fit in LDS */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the kernel without workgroup-level path reordering */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
@@ -161,7 +162,7 @@ typedef struct rt1w_stats {
     uint32_t chunk, n_chunks;
     uint32_t grid, block;
     uint32_t variant;      /* kernel variant used (V0..V3) */
-    uint32_t sorted;       /* 1: the reordering kernel ran */
+    uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: the LDS node cache was used */
 } rt1w_stats;
 
 /* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */

@@ -59,6 +59,21 @@ struct LdsStack {
     __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
     __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
 };
+/* 16-bit entries (node index < 32768, wrapper-exit flag in bit 15): half the LDS, used together with
+ * the LDS node cache */
+struct LdsStack16 {
+    uint16_t* base;
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); ++sp; }
+    __device__ __forceinline__ uint32_t pop() { --sp; uint32_t x = base[sp * RT_BLOCK]; return (x & 0x7FFFu) | ((x & 0x8000u) ? RT_POP_FLAG : 0u); }
+};
+/* hot halves of all nodes copied into LDS once per workgroup (scenes of <= RT_LDS_NODE_CAP nodes): the
+ * stack walk's dependent node fetches then cost LDS latency instead of L2/HBM latency */
+#define RT_LDS_NODE_CAP 1024
+struct LdsNodes {
+    const RtNodeHot* base;
+    __device__ __forceinline__ RtNodeHot hot(uint32_t n) const { return base[n]; }
+};
 
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -68,15 +83,27 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 #ifndef RT_SWEEP_WAVES
 #define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
 #endif
-template <class Cfg>
+template <class Cfg, bool CACHE = false>
 __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : 2) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                             unsigned long long* __restrict__ counters) {
     /* the sweep variants need no traversal stack (and no LDS at all) */
-    __shared__ uint32_t stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
-    LdsStack stk;
+    typedef typename std::conditional<CACHE, uint16_t, uint32_t>::type stack_word;
+    __shared__ stack_word stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
+    __shared__ RtNodeHot node_cache[CACHE ? RT_LDS_NODE_CAP : 1];
+    typename std::conditional<CACHE, LdsStack16, LdsStack>::type stk;
     stk.base = stack_mem + threadIdx.x;
     stk.sp = 0;
-    RtGlobalNodes ns{sc.nodes};
+    typename std::conditional<CACHE, LdsNodes, RtGlobalNodes>::type ns;
+    if constexpr (CACHE) {
+        /* cooperative copy: 16 bytes per lane per step */
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
+        uint4* dst = reinterpret_cast<uint4*>(node_cache);
+        for (uint32_t i = threadIdx.x; i < sc.n_nodes * 4u; i += RT_BLOCK) dst[i] = src[(i >> 2) * 6u + (i & 3u)]; /* 96-B records, first 64 B */
+        __syncthreads();
+        ns.base = node_cache;
+    } else {
+        ns.p = sc.nodes;
+    }
 
 #ifdef RT_STAMPS
     if ((threadIdx.x & 63) == 0) {
@@ -373,6 +400,7 @@ struct rt1w_context {
     unsigned long long* d_counters = nullptr;
     int grid[RT_N_VARIANTS] = {0, 0, 0, 0};
     int grid_sorted[RT_N_VARIANTS] = {0, 0, 0, 0};
+    int grid_cached[RT_N_VARIANTS] = {0, 0, 0, 0};
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
@@ -381,6 +409,8 @@ struct rt1w_context {
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
 static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV0>, rt_render_kernel<RtCfgV1>,
                                                          rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>};
+/* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes) */
+static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>};
 /* the reordering kernel exists for the variants where it pays (measured): the sweep variants */
 static render_kernel_t const g_kernels_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted<RtCfgV0>, rt_render_kernel_sorted<RtCfgV1>,
                                                                 nullptr, nullptr}; /* stack variants: measured 0.55x (LDS for stack + exchange halves occupancy) */
@@ -431,13 +461,14 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
         }
     }
     const bool sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
-    const int grid = sorted ? c->grid_sorted[variant] : c->grid[variant];
+    const bool cached = !sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && !(p->flags & RT1W_NO_LDS_NODES);
+    const int grid = sorted ? c->grid_sorted[variant] : (cached ? c->grid_cached[variant] : c->grid[variant]);
     const int block = sorted ? RT_SORT_BLOCK : RT_BLOCK;
     unsigned long long init[2] = {(unsigned long long)grid * block, 0ull};
     if (!hip_ok(hipMemcpyAsync(c->d_counters, init, sizeof init, hipMemcpyHostToDevice, c->stream), "counter init")) return RT1W_ERR_DEVICE;
     if (!hip_ok(hipStreamSynchronize(c->stream), "counter init sync")) return RT1W_ERR_DEVICE;
     (void)hipEventRecord(c->ev0, c->stream);
-    hipLaunchKernelGGL(sorted ? g_kernels_sorted[variant] : g_kernels[variant], dim3(grid), dim3(block), 0, c->stream, c->view, f,
+    hipLaunchKernelGGL(sorted ? g_kernels_sorted[variant] : (cached ? g_kernels_cached[variant] : g_kernels[variant]), dim3(grid), dim3(block), 0, c->stream, c->view, f,
                        c->d_partial, c->d_counters);
     {
         unsigned int rb = 256;
@@ -458,7 +489,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
         stats->kernel_ms = ms;
         stats->chunk = f.chunk; stats->n_chunks = f.n_chunks;
         stats->grid = (uint32_t)grid; stats->block = (uint32_t)block;
-        stats->variant = (uint32_t)variant; stats->sorted = sorted ? 1u : 0u;
+        stats->variant = (uint32_t)variant; stats->sorted = (sorted ? 1u : 0u) | (cached ? 2u : 0u);
     }
     return RT1W_OK;
 }
@@ -526,6 +557,14 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
         }
         if (per_cu < 1) per_cu = 1;
         c->grid[v] = prop.multiProcessorCount * per_cu;
+        if (g_kernels_cached[v]) {
+            per_cu = 0;
+            if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_cached[v], RT_BLOCK, 0), "occupancy query")) {
+                rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+            }
+            if (per_cu < 1) per_cu = 1;
+            c->grid_cached[v] = prop.multiProcessorCount * per_cu;
+        }
         if (g_kernels_sorted[v]) {
             per_cu = 0;
             if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_sorted[v], RT_SORT_BLOCK, 0), "occupancy query")) {

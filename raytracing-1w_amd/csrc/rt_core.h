@@ -181,7 +181,8 @@ RT_HD bool rt_prim_t(const RtNode& nd, uint32_t kind, RtV3 o, RtV3 d, double tim
 }
 
 /* Translate::hit hittable.rs:207-211 / RotateY::hit hittable.rs:238-251: ray into the wrapper's space */
-RT_HD RtRayOD rt_scope_in(const RtNode& s, RtRayOD r) {
+template <class NodeT>
+RT_HD RtRayOD rt_scope_in(const NodeT& s, RtRayOD r) {
     if (s.kind == RT_TRANSLATE) {
         r.o = r.o - rt_v3(s.d[0], s.d[1], s.d[2]);
     } else if (s.kind == RT_ROTATE_Y) {
@@ -325,6 +326,20 @@ RT_HD bool rt_prim_hot_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d, dou
     return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t_out);
 }
 
+/* static sphere / rects from the hot half when the kind differs per lane (stack walk): axis by select */
+RT_HD bool rt_prim_hot_sel_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d, double t_min, double t_max, double& t_out) {
+    if (kind >= RT_XY) {
+        double oa = kind == RT_XY ? o.z : (kind == RT_XZ ? o.y : o.x);
+        double da = kind == RT_XY ? d.z : (kind == RT_XZ ? d.y : d.x);
+        double ob = kind == RT_YZ ? o.y : o.x;
+        double db = kind == RT_YZ ? d.y : d.x;
+        double oc = kind == RT_XY ? o.y : o.z;
+        double dc = kind == RT_XY ? d.y : d.z;
+        return rt_rect_hot_t(nd, oa, da, ob, db, oc, dc, t_min, t_max, t_out);
+    }
+    return rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], o, d, t_min, t_max, t_out);
+}
+
 /* Where the sweep gets the hot half of node n (n is wave-uniform):
  *  - RtGlobalNodes: from memory (scalar loads on the GPU);
  *  - a lane-resident source (context.hip, scenes of <= 64 nodes): lane i of every wave keeps
@@ -362,8 +377,8 @@ RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_
  * and leaf work was measured 0.6x).  Visiting order is the reference's (bvh.rs:38-47).
  * MEDIA=false is the flavour used for a ConstantMedium's boundary, where only t is
  * consumed (constant_medium.rs:62-69). */
-template <class Cfg, bool MEDIA, class Stack>
-RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& world, double t_min,
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
                              uint32_t& out_scope) {
     const RtNode* nodes = sc.nodes;
@@ -387,7 +402,7 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
             else { cur = rt_ray_in_scope(nodes, scope, w); inv = rt_inv3(cur.d); }
             continue;
         }
-        const RtNode& nd = nodes[e];
+        const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes: from HBM/L2, or from the LDS copy */
         uint32_t kind = nd.kind & RT_KIND_MASK;
         if (kind <= RT_BVH1) {
             bool hit;
@@ -399,9 +414,10 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
             }
         } else if (kind <= RT_YZ) {
             double t;
-            if (rt_prim_t<Cfg>(nd, kind, cur.o, cur.d, world.time, t_min, best_t, t)) {
-                best_t = t; best_prim = e; best_scope = scope;
-            }
+            bool hit;
+            if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[e], kind, cur.o, cur.d, world.time, t_min, best_t, t);
+            else hit = rt_prim_hot_sel_t(nd, kind, cur.o, cur.d, t_min, best_t, t);
+            if (hit) { best_t = t; best_prim = e; best_scope = scope; }
         } else if (kind <= RT_FLIP) {
             stk.push(e | RT_POP_FLAG);
             scope = e;
@@ -413,9 +429,9 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, uint32_t root, const RtRay& 
         } else if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
             RtRay br; br.o = cur.o; br.d = cur.d; br.time = world.time;
             double t1, t2, t; uint32_t p_, s_;
-            if (!rt_traverse_stack<Cfg, false>(sc, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_)) continue;
-            if (!rt_traverse_stack<Cfg, false>(sc, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_)) continue;
-            if (rt_medium_t(nd, cur.d, t1, t2, t_min, best_t, rng, t)) {
+            if (!rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_)) continue;
+            if (!rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_)) continue;
+            if (rt_medium_t(nodes[e], cur.d, t1, t2, t_min, best_t, rng, t)) {
                 best_t = t; best_prim = e; best_scope = scope;
             }
         }
@@ -518,7 +534,7 @@ template <class Cfg, class Stack, class NS>
 RT_HD bool rt_closest_hit(const RtSceneView& sc, const NS& ns, const RtRay& ray, double t_min, double t_max, RtRng& rng,
                           Stack& stk, double& t, uint32_t& prim, uint32_t& scope) {
     if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, t, prim, scope);
-    else return rt_traverse_stack<Cfg, true>(sc, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
+    else return rt_traverse_stack<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
 }
 
 /* ------------------------------------------------------------ textures -- */
@@ -771,7 +787,7 @@ RT_HD RtTrace rt_path_trace(const RtSceneView& sc, const NS& ns, RtPath& p, Stac
     bool found = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, tr.t, tr.prim, tr.scope);
     RT_STAMP(2);
     if (!found) { tr.prim = RT_NONE; return tr; }
-    uint32_t mk = sc.materials[sc.nodes[tr.prim].mat].kind & 0xFFu;
+    uint32_t mk = sc.materials[ns.hot(tr.prim).mat].kind & 0xFFu;
     tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT
            : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
            : mk == RT_MAT_METAL ? RT_CLS_METAL
