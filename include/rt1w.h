@@ -139,7 +139,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out);
 void rt1w_context_destroy(rt1w_context* c);
 
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
-#define RT1W_NO_LDS_NODES 4u /* tests/ablation: stack variants fetch nodes from memory even when the hot halves would fit in LDS */
+#define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the kernel without workgroup-level path reordering */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 

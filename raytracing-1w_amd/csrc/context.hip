@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 #define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
 #endif
 template <class Cfg, bool CACHE = false>
-__global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : 2) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+__global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : (Cfg::sweep || CACHE ? 2 : 3)) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                             unsigned long long* __restrict__ counters) {
     /* the sweep variants need no traversal stack (and no LDS at all) */
     typedef typename std::conditional<CACHE, uint16_t, uint32_t>::type stack_word;
@@ -409,7 +409,8 @@ struct rt1w_context {
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
 static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV0>, rt_render_kernel<RtCfgV1>,
                                                          rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>};
-/* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes) */
+/* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
+ * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
 static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>};
 /* the reordering kernel exists for the variants where it pays (measured): the sweep variants */
 static render_kernel_t const g_kernels_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted<RtCfgV0>, rt_render_kernel_sorted<RtCfgV1>,
@@ -461,7 +462,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
         }
     }
     const bool sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
-    const bool cached = !sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && !(p->flags & RT1W_NO_LDS_NODES);
+    const bool cached = !sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
     const int grid = sorted ? c->grid_sorted[variant] : (cached ? c->grid_cached[variant] : c->grid[variant]);
     const int block = sorted ? RT_SORT_BLOCK : RT_BLOCK;
     unsigned long long init[2] = {(unsigned long long)grid * block, 0ull};

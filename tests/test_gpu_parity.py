@@ -130,19 +130,20 @@ def test_sorted_and_unsorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
 
 
 def test_lds_node_cache_is_bit_identical(rt, gpu_ctx_factory):
-    """Stack variants on scenes of <= 1024 nodes read node records from an LDS copy (16-bit stack entries): same bits."""
+    """Opt-in experiment: stack variants on scenes of <= 1024 nodes reading node records from an LDS copy (16-bit stack
+    entries): same bits as the default."""
     for arm, (W, H, spp) in ((0, (96, 64, 8)),):
         sc = rt.Scene.reference(arm, build_seed=1)
         ctx = gpu_ctx_factory(sc)
-        a, sa = ctx.render(W, H, spp, no_lds_nodes=True)
-        b, sb = ctx.render(W, H, spp)
+        a, sa = ctx.render(W, H, spp)
+        b, sb = ctx.render(W, H, spp, lds_nodes=True)
         assert (sa["sorted"] & 2) == 0 and (sb["sorted"] & 2) == 2
         assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True)
     # a user scene with media + wrappers forced onto the stack variant V3 (cached, 16-bit stack with wrapper-exit markers)
     sc = rt.Scene.reference(6, build_seed=1)
     ctx = gpu_ctx_factory(sc)
-    a, sa = ctx.render(64, 64, 8, variant=3, no_lds_nodes=True)
-    b, sb = ctx.render(64, 64, 8, variant=3)
+    a, sa = ctx.render(64, 64, 8, variant=3)
+    b, sb = ctx.render(64, 64, 8, variant=3, lds_nodes=True)
     c, sc_ = ctx.render(64, 64, 8)
     assert (sb["sorted"] & 2) == 2 and np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
 
