@@ -140,7 +140,7 @@ void rt1w_context_destroy(rt1w_context* c);
 
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
-#define RT1W_UNSORTED 2u  /* tests/ablation: use the kernel without workgroup-level path reordering */
+#define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering) */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
 typedef struct rt1w_render_params {
@@ -162,7 +162,7 @@ typedef struct rt1w_stats {
     uint32_t chunk, n_chunks;
     uint32_t grid, block;
     uint32_t variant;      /* kernel variant used (V0..V3) */
-    uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: the LDS node cache was used */
+    uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: LDS node cache */
 } rt1w_stats;
 
 /* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */

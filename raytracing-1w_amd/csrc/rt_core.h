@@ -370,74 +370,104 @@ RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_
     return true;
 }
 
-/* Closest hit of the subtree `root` for `world` (a ray in the subtree's outer
- * space) within [t_min, t_max], with an explicit per-lane stack (LDS on the GPU).
- * One entry per iteration whatever its kind: the walk is bound by the latency of the
- * dependent node fetches, so the fewest iterations win (a "while-while" split of box
- * and leaf work was measured 0.6x).  Visiting order is the reference's (bvh.rs:38-47).
- * MEDIA=false is the flavour used for a ConstantMedium's boundary, where only t is
+/* Closest hit of a subtree for a ray within [t_min, t_max], with an explicit per-lane stack (LDS
+ * on the GPU), written as a resumable walk: rt_walk_begin pushes the root, rt_walk_step handles ONE
+ * stack entry whatever its kind, rt_walk_done says when the stack is back to its base.  (A kernel
+ * that ran one step per iteration and let finished lanes shade in batches while the others kept
+ * walking was measured: it only ties the plain loop at equal occupancy and needs more registers.)
+ * The walk is bound by the latency of the dependent node fetches, so the fewest iterations win (a
+ * "while-while" split of box and leaf work was measured 0.6x).
+ * Visiting order is the reference's (bvh.rs:38-47): left subtree, then right subtree with the
+ * closest t so far as t_max. */
+struct RtWalk {
+    RtRayOD w;          /* the ray in the subtree's outer space */
+    RtRayOD cur;        /* the ray in the current wrapper's space */
+    RtV3 inv_w, inv;    /* 1/direction of w and of cur */
+    double time, t_min, best_t;
+    uint32_t scope, best_prim, best_scope;
+    int base;           /* stack level at entry */
+    bool tmin_nan;
+};
+
+template <class Stack>
+RT_HD void rt_walk_begin(RtWalk& k, uint32_t root, const RtRay& world, double t_min, double t_max, Stack& stk) {
+    k.w.o = world.o; k.w.d = world.d;
+    k.cur = k.w;
+    k.inv_w = rt_inv3(k.w.d);
+    k.inv = k.inv_w;
+    k.time = world.time; k.t_min = t_min; k.best_t = t_max;
+    k.scope = RT_NONE; k.best_prim = RT_NONE; k.best_scope = RT_NONE;
+    k.tmin_nan = rt_isnan(t_min);
+    k.base = stk.sp;
+    stk.push(root);
+}
+template <class Stack>
+RT_HD bool rt_walk_done(const RtWalk& k, const Stack& stk) { return stk.sp <= k.base; }
+
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
+                             double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
+                             uint32_t& out_scope);
+
+/* one stack entry.  MEDIA=false is the flavour used for a ConstantMedium's boundary, where only t is
  * consumed (constant_medium.rs:62-69). */
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
+    const RtNode* nodes = sc.nodes;
+    uint32_t e = stk.pop();
+    if (e & RT_POP_FLAG) {
+        /* leaving a wrapper: back to the parent's ray (recomputed from the outer ray by the
+         * same operations that produced it, hence the same bits) */
+        k.scope = nodes[e & ~RT_POP_FLAG].b;
+        if (k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
+        else { k.cur = rt_ray_in_scope(nodes, k.scope, k.w); k.inv = rt_inv3(k.cur.d); }
+        return;
+    }
+    const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
+    uint32_t kind = nd.kind & RT_KIND_MASK;
+    if (kind <= RT_BVH1) {
+        bool hit;
+        if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+        else hit = rt_aabb_hit_fast(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+        if (hit) {
+            if (kind == RT_BVH2) stk.push(nd.b);
+            stk.push(e + 1u); /* left child / only child: the next node in pre-order */
+        }
+    } else if (kind <= RT_YZ) {
+        double t;
+        bool hit;
+        if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[e], kind, k.cur.o, k.cur.d, k.time, k.t_min, k.best_t, t);
+        else hit = rt_prim_hot_sel_t(nd, kind, k.cur.o, k.cur.d, k.t_min, k.best_t, t);
+        if (hit) { k.best_t = t; k.best_prim = e; k.best_scope = k.scope; }
+    } else if (kind <= RT_FLIP) {
+        stk.push(e | RT_POP_FLAG);
+        k.scope = e;
+        if (kind != RT_FLIP) {
+            k.cur = rt_scope_in(nd, k.cur);
+            if (kind == RT_ROTATE_Y) k.inv = rt_inv3(k.cur.d);
+        }
+        stk.push(e + 1u);
+    } else if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
+        /* ConstantMedium::hit constant_medium.rs:58-113: two complete boundary walks, then the free-flight draw */
+        RtRay br; br.o = k.cur.o; br.d = k.cur.d; br.time = k.time;
+        double t1, t2, t; uint32_t p_, s_;
+        if (rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_) &&
+            rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_) &&
+            rt_medium_t(nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
+            k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
+        }
+    }
+}
+
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
                              uint32_t& out_scope) {
-    const RtNode* nodes = sc.nodes;
-    RtRayOD w; w.o = world.o; w.d = world.d;
-    RtRayOD cur = w;
-    const RtV3 inv_w = rt_inv3(w.d);
-    RtV3 inv = inv_w;
-    uint32_t scope = RT_NONE;
-    double best_t = t_max;
-    uint32_t best_prim = RT_NONE, best_scope = RT_NONE;
-    const bool tmin_nan = rt_isnan(t_min);
-    const int base = stk.sp;
-    stk.push(root);
-    while (stk.sp > base) {
-        uint32_t e = stk.pop();
-        if (e & RT_POP_FLAG) {
-            /* leaving a wrapper: back to the parent's ray (recomputed from the
-             * outer ray by the same operations that produced it, hence the same bits) */
-            scope = nodes[e & ~RT_POP_FLAG].b;
-            if (scope == RT_NONE) { cur = w; inv = inv_w; }
-            else { cur = rt_ray_in_scope(nodes, scope, w); inv = rt_inv3(cur.d); }
-            continue;
-        }
-        const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes: from HBM/L2, or from the LDS copy */
-        uint32_t kind = nd.kind & RT_KIND_MASK;
-        if (kind <= RT_BVH1) {
-            bool hit;
-            if (RT_WAVE_ANY(tmin_nan || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, cur.o, inv, t_min, best_t);
-            else hit = rt_aabb_hit_fast(nd.d, cur.o, inv, t_min, best_t);
-            if (hit) {
-                if (kind == RT_BVH2) stk.push(nd.b);
-                stk.push(e + 1u); /* left child / only child: the next node in pre-order */
-            }
-        } else if (kind <= RT_YZ) {
-            double t;
-            bool hit;
-            if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[e], kind, cur.o, cur.d, world.time, t_min, best_t, t);
-            else hit = rt_prim_hot_sel_t(nd, kind, cur.o, cur.d, t_min, best_t, t);
-            if (hit) { best_t = t; best_prim = e; best_scope = scope; }
-        } else if (kind <= RT_FLIP) {
-            stk.push(e | RT_POP_FLAG);
-            scope = e;
-            if (kind != RT_FLIP) {
-                cur = rt_scope_in(nd, cur);
-                if (kind == RT_ROTATE_Y) inv = rt_inv3(cur.d);
-            }
-            stk.push(e + 1u);
-        } else if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
-            RtRay br; br.o = cur.o; br.d = cur.d; br.time = world.time;
-            double t1, t2, t; uint32_t p_, s_;
-            if (!rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_)) continue;
-            if (!rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_)) continue;
-            if (rt_medium_t(nodes[e], cur.d, t1, t2, t_min, best_t, rng, t)) {
-                best_t = t; best_prim = e; best_scope = scope;
-            }
-        }
-    }
-    out_t = best_t; out_prim = best_prim; out_scope = best_scope;
-    return best_prim != RT_NONE;
+    RtWalk k;
+    rt_walk_begin(k, root, world, t_min, t_max, stk);
+    while (!rt_walk_done(k, stk)) rt_walk_step<Cfg, MEDIA>(sc, ns, k, rng, stk);
+    out_t = k.best_t; out_prim = k.best_prim; out_scope = k.best_scope;
+    return k.best_prim != RT_NONE;
 }
 
 /* The same traversal without a stack, for small scenes.  Nodes are stored in
