@@ -294,3 +294,40 @@ def test_c5_4k_cornell_tiles(rt, gpu_ctx_factory):
     crop = (1900, y0 + 4, 8, 4)
     b, _ = orc.flat_render(sc, W, H, 200, tile=crop, chunk=st["chunk"])
     assert np.array_equal(strip[4:8, 1900:1908], b)
+
+
+def test_two_contexts_render_concurrently_from_two_threads(rt, gpu_ctx_factory):
+    """include/rt1w.h: calls on distinct contexts are thread-safe (one host thread per context / GPU)."""
+    import threading
+    sc5 = rt.Scene.reference(5, build_seed=1)
+    sc0 = rt.Scene.reference(0, build_seed=1)
+    c5, c0 = gpu_ctx_factory(sc5), gpu_ctx_factory(sc0)
+    ref5, _ = c5.render(128, 128, 16)
+    ref0, _ = c0.render(96, 64, 8)
+    out = {}
+
+    def work(name, ctx, args, n):
+        res = []
+        for _ in range(n):
+            img, _ = ctx.render(*args)
+            res.append(img)
+        out[name] = res
+
+    th = [threading.Thread(target=work, args=("a", c5, (128, 128, 16), 6)), threading.Thread(target=work, args=("b", c0, (96, 64, 8), 6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(np.array_equal(i, ref5) for i in out["a"]) and all(np.array_equal(i, ref0) for i in out["b"])
+
+
+def test_cli_writes_the_reference_ppm_layout(rt, tmp_path):
+    """raytracing-1w_amd/rt1w: the `main` of the reference with the pixel loop on the GPU; its P3 text must equal
+    what the library/oracle produce for the same parameters."""
+    import subprocess
+    exe = os.path.join(orc.ROOT, "raytracing-1w_amd", "rt1w")
+    assert os.path.exists(exe)
+    out = tmp_path / "o.ppm"
+    subprocess.check_call([exe, "--scene", "5", "--width", "48", "--height", "48", "--spp", "8", "--out", str(out)], stderr=subprocess.DEVNULL)
+    lit, _ = orc.OracleScene(5, build_seed=1).render(48, 48, 8)
+    assert out.read_text() == rt.format_ppm(lit)
