@@ -177,6 +177,12 @@ int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, r
  * tensor); no host copy.  Synchronises the context's stream before returning. */
 int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out_rgb, rt1w_stats* stats);
 
+/* same render, but the tile comes back already quantised ON THE DEVICE exactly as the reference prints it
+ * (Display for SampledColor src/color.rs:56-65: (256 * sqrt(c).clamp(0, 0.999)) as usize) and in the reference's row
+ * order (top row = j = y0 + tile_h - 1 first, src/main.rs:957-960,1003-1007): out_rgb8[tile_h][tile_w][3].  No host
+ * post-pass, 1/8 of the device->host bytes.   */
+int rt1w_render_u8(rt1w_context* c, const rt1w_render_params* p, uint8_t* out_rgb8, rt1w_stats* stats);
+
 /* ---- output side (src/color.rs) ---- */
 
 /* Color::into_sampled (color.rs:14-21) over n pixels: NaN scrub of the SUM, then * 1/spp */

@@ -113,6 +113,7 @@ _sig("rt1w_context_destroy", None, _P)
 _sig("rt1w_default_chunk", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("rt1w_render", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
+_sig("rt1w_render_u8", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_resolve", C.c_int, _P, C.c_uint64, C.c_uint32, _P)
 _sig("rt1w_quantize", C.c_int, _P, C.c_uint64, _P)
 _sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
@@ -309,6 +310,14 @@ class Context:
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
         st = Stats()
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
+        return out, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def render_u8(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0):
+        """Quantised on the device, rows top-down as the reference prints them: uint8 [tile_h, tile_w, 3]."""
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, False)
+        out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.uint8)
+        st = Stats()
+        _ck(_lib.rt1w_render_u8(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
     def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0,

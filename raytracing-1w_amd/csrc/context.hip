@@ -350,6 +350,19 @@ __global__ void rt_resolve_kernel(const double* __restrict__ partial, double* __
     out[p * 3 + 0] = total.x; out[p * 3 + 1] = total.y; out[p * 3 + 2] = total.z;
 }
 
+/* Display for SampledColor (src/color.rs:56-65) on the device: gamma-2, clamp, *256, truncate; rows flipped into the
+ * order the reference prints them (j = height-1 first, src/main.rs:957-960,1003-1007).  in = means [tile_h][tile_w][3] f64
+ * (row 0 = j = y0), out = [tile_h][tile_w][3] u8 top-down. */
+__global__ void rt_quantize_kernel(const double* __restrict__ means, uint8_t* __restrict__ out, uint32_t w, uint32_t h) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n = (unsigned long long)w * h;
+    if (i >= n) return;
+    uint32_t row = (uint32_t)(i / w), col = (uint32_t)(i % w);
+    const double* src = means + ((unsigned long long)(h - 1u - row) * w + col) * 3ull;
+    uint8_t* dst = out + i * 3ull;
+    dst[0] = (uint8_t)rt_quantize(src[0]); dst[1] = (uint8_t)rt_quantize(src[1]); dst[2] = (uint8_t)rt_quantize(src[2]);
+}
+
 /* AABB slab test on the device, both forms, for tests: in[i] = {bb[6], o[3], d[3], t_min, t_max} */
 __global__ void rt_debug_aabb_kernel(const double* in, int* out_literal, int* out_fast, unsigned long long n) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -604,6 +617,31 @@ int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out
     rc = render_common(c, p, (double*)d_out_rgb, stats);
     if (rc == RT1W_OK && stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
+}
+
+int rt1w_render_u8(rt1w_context* c, const rt1w_render_params* p, uint8_t* out_rgb8, rt1w_stats* stats) {
+    int rc = validate(c, p);
+    if (rc < 0) return rc;
+    if (!out_rgb8) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
+    if (p->flags & RT1W_OUT_SUM) { rt1w::set_error("RT1W_OUT_SUM has no 8-bit form"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    auto t0 = std::chrono::steady_clock::now();
+    size_t npix = (size_t)p->tile_w * p->tile_h;
+    size_t bytes = npix * 3 * sizeof(double) + npix * 3; /* framebuffer + quantised image behind it */
+    if (bytes > c->out_bytes) {
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_out = nullptr; c->out_bytes = 0;
+        if (!hip_ok(hipMalloc((void**)&c->d_out, bytes), "hipMalloc(framebuffer)")) return RT1W_ERR_NOMEM;
+        c->out_bytes = bytes;
+    }
+    rc = render_common(c, p, c->d_out, stats);
+    if (rc < 0) return rc;
+    uint8_t* d_u8 = reinterpret_cast<uint8_t*>(c->d_out + npix * 3);
+    hipLaunchKernelGGL(rt_quantize_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, c->d_out, d_u8, p->tile_w, p->tile_h);
+    if (!hip_ok(hipMemcpyAsync(out_rgb8, d_u8, npix * 3, hipMemcpyDeviceToHost, c->stream), "quantised image copy") ||
+        !hip_ok(hipStreamSynchronize(c->stream), "quantise kernel")) return RT1W_ERR_DEVICE;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT1W_OK;
 }
 
 int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, rt1w_stats* stats) {

@@ -331,3 +331,18 @@ def test_cli_writes_the_reference_ppm_layout(rt, tmp_path):
     subprocess.check_call([exe, "--scene", "5", "--width", "48", "--height", "48", "--spp", "8", "--out", str(out)], stderr=subprocess.DEVNULL)
     lit, _ = orc.OracleScene(5, build_seed=1).render(48, 48, 8)
     assert out.read_text() == rt.format_ppm(lit)
+
+
+def test_device_side_quantiser_matches_host(rt, gpu_ctx_factory):
+    """rt1w_render_u8: bytes == host rt1w_quantize of the f64 render, rows top-down; also on a
+    framebuffer with NaN-scrubbed / over-bright / zero pixels (depth 1: only the light, saturating at 255)."""
+    ctx = gpu_ctx_factory(rt.Scene.reference(5, build_seed=1))
+    for (W, H, spp, tile, depth) in ((96, 64, 8, None, 50), (50, 50, 3, (7, 9, 13, 5), 50), (64, 64, 4, None, 1)):
+        img, _ = ctx.render(W, H, spp, tile=tile, max_depth=depth)
+        u8, _ = ctx.render_u8(W, H, spp, tile=tile, max_depth=depth)
+        assert u8.dtype == np.uint8 and np.array_equal(u8, rt.quantize(img)[::-1])
+    # and the P3 text assembled from the device bytes equals the reference layout
+    img, _ = ctx.render(40, 30, 4)
+    u8, _ = ctx.render_u8(40, 30, 4)
+    txt = "P3\n40 30\n255\n" + "".join("%d %d %d\n" % tuple(px) for row in u8 for px in row)
+    assert txt == rt.format_ppm(img)
