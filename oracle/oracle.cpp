@@ -1083,7 +1083,7 @@ using namespace orc;
 
 extern "C" {
 
-struct orc_scene { Scene s; };
+struct orc_scene { Scene s; std::vector<MatPtr> keep_mats; std::vector<TexPtr> keep_tex; };
 
 /* returns NULL on the reference's panics */
 orc_scene* orc_scene_build(int arm, uint64_t build_seed, double aspect_ratio, const uint8_t* earth, uint32_t ew, uint32_t eh, uint32_t defaults[3]) {
@@ -1151,6 +1151,80 @@ void orc_resolve(const double* sums, uint64_t n, uint32_t spp, double* means) {
     for (uint64_t i = 0; i < n; ++i) { V3 m = into_sampled(rt_v3(sums[i * 3], sums[i * 3 + 1], sums[i * 3 + 2]), spp); means[i * 3] = m.x; means[i * 3 + 1] = m.y; means[i * 3 + 2] = m.z; }
 }
 void orc_quantize(const double* means, uint64_t n, uint8_t* out) { for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)quantize(means[i]); }
+
+/* ---- generic scene builder (tests build arbitrary graphs in the oracle and, call for call, through the product's
+ * C ABI; ids are indices into the builder's tables; a hittable id is consumed by the parent that takes it) ---- */
+struct orc_builder {
+    MyRng rng;
+    std::vector<TexPtr> tex;
+    std::vector<MatPtr> mat;
+    std::vector<HBox> hit;
+    std::unique_ptr<HittableList> lights;
+    std::unique_ptr<BVHNode> world;
+    V3 background;
+    Camera camera;
+};
+orc_builder* orcb_new(uint64_t build_seed) { orc_builder* b = new orc_builder(); b->rng = rt_rng_build(build_seed); b->background = rt_v3(0, 0, 0); return b; }
+void orcb_free(orc_builder* b) { delete b; }
+double orcb_rng_f64(orc_builder* b) { return rt_gen_f64(b->rng); }
+double orcb_rng_range(orc_builder* b, double lo, double hi) { return rt_gen_range(b->rng, lo, hi); }
+int orcb_tex_solid(orc_builder* b, double r, double g, double bl) { b->tex.push_back(solid(r, g, bl)); return (int)b->tex.size() - 1; }
+int orcb_tex_checker(orc_builder* b, int odd, int even) { b->tex.push_back(TexPtr(new CheckerTexture(b->tex[odd], b->tex[even]))); return (int)b->tex.size() - 1; }
+int orcb_tex_noise(orc_builder* b, double scale) { b->tex.push_back(TexPtr(new NoiseTexture(scale, b->rng))); return (int)b->tex.size() - 1; }
+int orcb_tex_image(orc_builder* b, const uint8_t* rgb, uint32_t w, uint32_t h) { b->tex.push_back(TexPtr(new ImageTexture(rgb, w, h))); return (int)b->tex.size() - 1; }
+int orcb_mat_lambertian(orc_builder* b, int t) { b->mat.push_back(lambert(b->tex[t])); return (int)b->mat.size() - 1; }
+int orcb_mat_metal(orc_builder* b, double r, double g, double bl, double fuzz) { b->mat.push_back(MatPtr(new Metal(rt_v3(r, g, bl), fuzz))); return (int)b->mat.size() - 1; }
+int orcb_mat_dielectric(orc_builder* b, double ir) { b->mat.push_back(MatPtr(new Dielectric(ir))); return (int)b->mat.size() - 1; }
+int orcb_mat_diffuse_light(orc_builder* b, int t) { b->mat.push_back(MatPtr(new DiffuseLight(b->tex[t]))); return (int)b->mat.size() - 1; }
+int orcb_mat_null(orc_builder* b) { b->mat.push_back(MatPtr(new NullMaterial())); return (int)b->mat.size() - 1; }
+static int orcb_push(orc_builder* b, Hittable* h) { b->hit.emplace_back(h); return (int)b->hit.size() - 1; }
+int orcb_sphere(orc_builder* b, double x, double y, double z, double r, int m) { return orcb_push(b, new Sphere(rt_v3(x, y, z), r, b->mat[m])); }
+int orcb_moving_sphere(orc_builder* b, const double* c0, const double* c1, double t0, double t1, double r, int m) {
+    return orcb_push(b, new MovingSphere(rt_v3(c0[0], c0[1], c0[2]), rt_v3(c1[0], c1[1], c1[2]), t0, t1, r, b->mat[m]));
+}
+int orcb_rect(orc_builder* b, int axis, double a0, double a1, double b0, double b1, double k, int m) {
+    if (axis == 0) return orcb_push(b, new XYRect(a0, a1, b0, b1, k, b->mat[m]));
+    if (axis == 1) return orcb_push(b, new XZRect(a0, a1, b0, b1, k, b->mat[m]));
+    return orcb_push(b, new YZRect(a0, a1, b0, b1, k, b->mat[m]));
+}
+int orcb_aabox(orc_builder* b, const double* p0, const double* p1, int m) {
+    return orcb_push(b, new AABox(rt_v3(p0[0], p0[1], p0[2]), rt_v3(p1[0], p1[1], p1[2]), b->mat[m], b->rng));
+}
+int orcb_translate(orc_builder* b, int c, double x, double y, double z) { return orcb_push(b, new Translate(std::move(b->hit[c]), rt_v3(x, y, z))); }
+int orcb_rotate_y(orc_builder* b, int c, double deg) { return orcb_push(b, new RotateY(std::move(b->hit[c]), 0.0, 1.0, deg)); }
+int orcb_flip_face(orc_builder* b, int c) { return orcb_push(b, new FlipFace(std::move(b->hit[c]))); }
+int orcb_constant_medium(orc_builder* b, int c, double d, int t) { return orcb_push(b, new ConstantMedium(std::move(b->hit[c]), d, b->tex[t])); }
+int orcb_bvh(orc_builder* b, const int* ids, uint32_t n) {
+    try {
+        std::vector<HBox> objs;
+        for (uint32_t i = 0; i < n; ++i) objs.push_back(std::move(b->hit[ids[i]]));
+        std::unique_ptr<BVHNode> node = BVHNode::make(std::move(objs), 0.0, 1.0, b->rng);
+        b->hit.push_back(std::move(node));
+        return (int)b->hit.size() - 1;
+    } catch (...) { return -1; }
+}
+void orcb_set_world(orc_builder* b, int id) { b->world.reset(static_cast<BVHNode*>(b->hit[id].release())); }
+void orcb_set_lights(orc_builder* b, const int* ids, uint32_t n) {
+    if (n == 0) { b->lights.reset(); return; }
+    b->lights.reset(new HittableList());
+    for (uint32_t i = 0; i < n; ++i) b->lights->items.push_back(std::move(b->hit[ids[i]]));
+}
+void orcb_set_background(orc_builder* b, double r, double g, double bl) { b->background = rt_v3(r, g, bl); }
+void orcb_set_camera(orc_builder* b, const double* from, const double* at, const double* vup, double vfov, double aspect, double aperture, double focus, double t0, double t1) {
+    b->camera = Camera(rt_v3(from[0], from[1], from[2]), rt_v3(at[0], at[1], at[2]), rt_v3(vup[0], vup[1], vup[2]), vfov, aspect, aperture, focus, t0, t1);
+}
+/* turn the builder into a renderable scene (consumes it) */
+orc_scene* orcb_finish(orc_builder* b) {
+    orc_scene* o = new orc_scene();
+    o->s.world = std::move(b->world);
+    o->s.lights = std::move(b->lights);
+    o->s.background = b->background;
+    o->s.camera = b->camera;
+    o->s.image_width = 0; o->s.samples_per_pixel = 0;
+    o->keep_mats = b->mat; o->keep_tex = b->tex;
+    delete b;
+    return o;
+}
 
 /* ---- leaf entry points for known-answer tests ---- */
 /* hit of one primitive: kind 0 sphere(c[3],r) 1 xy 2 xz 3 yz (a0,a1,b0,b1,k) 4 moving sphere (c0[3],c1[3],t0,t1,r).
