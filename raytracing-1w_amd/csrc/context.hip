@@ -214,8 +214,15 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT
     path.ray.time = 0.0;
     path.rng = rt_rng_make(0u, 0u, 0u, f.global_seed, RT_DOMAIN_RENDER);
     unsigned long long segs = 0;
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 16; ++k) rt_stamp_acc[threadIdx.x >> 6][k] = 0;
+        rt_stamp_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 
     for (;;) {
+        RT_STAMP(6);
         /* 1. regeneration: next sample of the lane's item, or a new item */
         if (!path.alive && !retired) {
             uint32_t s_end = chunk * f.chunk + f.chunk < f.spp ? chunk * f.chunk + f.chunk : f.spp;
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT
             if (!have) retired = true;
             else rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
         }
+        RT_STAMP(1);
         /* 2. closest hit + class */
         RtTrace tr;
         tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_IDLE;
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT
             segs += path.depth_left != 0u ? 1ull : 0ull;
             tr = rt_path_trace<Cfg>(sc, ns, path, stk);
         }
+        RT_STAMP(2);
         /* 3. sort the workgroup's paths by class */
         uint32_t my_rank = 0;
 #pragma unroll
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT
 #undef RT_GETD
 #undef RT_GET2
         }
+        RT_STAMP(7);
         /* 4. shading (coherent within a wave after the sort) */
         if (!retired) {
             rt_path_shade<Cfg>(sc, path, tr);
@@ -331,8 +341,13 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT
                 ++s;
             }
         }
+        RT_STAMP(5);
     }
     if (segs) atomicAdd(&counters[1], segs);
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 16; ++k) atomicAdd(&g_stamp_total[k], rt_stamp_acc[threadIdx.x >> 6][k]);
+#endif
 }
 
 /* Sum the chunk partials of each pixel in chunk order; then Color::into_sampled

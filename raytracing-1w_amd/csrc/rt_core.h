@@ -494,7 +494,6 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
     const bool tmin_nan = rt_isnan(t_min);
     const uint32_t end = ns.hot(root).skip;
     uint32_t cur = root;
-    RT_STAMP(8);
     for (uint32_t n = root; n < end; ++n) {
         const RtNodeHot nd = ns.hot(n);
         /* lanes whose wrapper's subtree ended before n go back to the parent's ray */
@@ -509,9 +508,8 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
                 else { cur_ray = rt_ray_in_scope(nodes, scope, w); inv = rt_inv3(cur_ray.d); }
             }
         }
-        RT_STAMP(9);
         bool active = (cur == n);
-        if (!RT_WAVE_ANY(active)) { RT_STAMP(10); continue; }
+        if (!RT_WAVE_ANY(active)) continue;
         const uint32_t kind = nd.kind & RT_KIND_MASK;
         if (active) {
             RT_STAT_VISIT(kind);
@@ -555,7 +553,6 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
                 cur = nd.skip;
             }
         }
-        RT_STAMP(kind <= RT_BVH1 ? 11 : (kind <= RT_YZ ? 12 : 13));
     }
     out_t = best_t; out_prim = best_prim; out_scope = best_scope;
     return best_prim != RT_NONE;
@@ -816,9 +813,7 @@ RT_HD RtTrace rt_path_trace(const RtSceneView& sc, const NS& ns, RtPath& p, Stac
     RtTrace tr;
     tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
     if (p.depth_left == 0u) return tr;
-    RT_STAMP(0);
     bool found = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, tr.t, tr.prim, tr.scope);
-    RT_STAMP(2);
     if (!found) { tr.prim = RT_NONE; return tr; }
     uint32_t mk = sc.materials[ns.hot(tr.prim).mat].kind & 0xFFu;
     tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT

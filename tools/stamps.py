@@ -5,7 +5,7 @@ import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import orc
 rt = orc.rt()
-names = ["loop/other", "regen", "traverse(rest)", "hit record", "shade lambert", "shade other", "bookkeeping", "-", "sweep setup", "sweep pop+hdr", "sweep idle step", "sweep bvh step", "sweep prim step", "sweep scope step", "-", "-"]
+names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+tail", "loop top", "sort+exchange+barriers", "sweep setup", "sweep pop+hdr", "sweep idle step", "sweep bvh step", "sweep prim step", "sweep scope step", "-", "-"]
 for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), (400, 400, 32)) for a in sys.argv[1:]):
     sc = rt.Scene.reference(arm)
     ctx = rt.Context(sc, 0)
