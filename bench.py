@@ -113,10 +113,13 @@ def main():
         algo_bytes = 2 * RECORD_BYTES * segs + 24 * W * H
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
+        pmc = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                prof = json.load(open(tp))
+                traffic = prof.get("hbm_bytes_per_launch")   # rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command (profiles/)
+                pmc = prof.get("pmc")
             except Exception:
                 traffic = None
         line = {
@@ -135,7 +138,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "rt_render_kernel_sorted<V%d>" % st["variant"] if (st.get("sorted", 0) & 1) else "rt_render_kernel<V%d>" % st["variant"],
                          "kernel_ms": round(avg_ms, 3),
-                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_launch": algo_bytes, "pmc": pmc,
                          "note": "compute-bound f64 kernel: ray state stays in VGPRs, so real HBM traffic is far "
                                  "below the algorithmic record traffic of SURVEY 8(d)"},
         }
