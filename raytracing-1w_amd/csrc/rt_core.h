@@ -347,14 +347,7 @@ RT_HD bool rt_prim_hot_sel_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d,
  *    v_readlane -- the traversal then touches no memory at all. */
 struct RtGlobalNodes {
     const RtNode* p;
-#if defined(__HIP_DEVICE_COMPILE__)
-    /* The scene is read-only for the whole launch: reading it through the constant address space lets
-     * the compiler keep the wave-uniform node fetch on the scalar unit whatever else the loop stores. */
-    typedef __attribute__((address_space(4))) const RtNodeHot* ConstHot;
-    RT_HD RtNodeHot hot(uint32_t n) const { return *(ConstHot)(uintptr_t)(p + n); }
-#else
     RT_HD RtNodeHot hot(uint32_t n) const { return *reinterpret_cast<const RtNodeHot*>(p + n); }
-#endif
 };
 
 /* ----------------------------------------------------------- traversal -- */
@@ -495,74 +488,69 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
     RtRayOD cur_ray = w;
     const RtV3 inv_w = rt_inv3(w.d);
     RtV3 inv = inv_w;
+    uint32_t scope = RT_NONE, scope_end = RT_NONE;
     double best_t = t_max;
     uint32_t best_prim = RT_NONE, best_scope = RT_NONE;
     const bool tmin_nan = rt_isnan(t_min);
     const uint32_t end = ns.hot(root).skip;
     uint32_t cur = root;
-    /* Wrappers are handled wave-wide: the wrapper nodes entered so far (s0 outermost) and where
-     * their subtrees end are the same for every lane that is inside, and a lane that skipped the
-     * wrapper is idle until past its end, so every lane just carries the wrapper-space ray along.
-     * Between two wrapper events the ray is loop-invariant. */
-    uint32_t s0 = RT_NONE, s1 = RT_NONE, s2 = RT_NONE, e0 = 0u, e1 = 0u, e2 = 0u, depth = 0u;
-    uint32_t n = root;
-    while (n < end) {
-        const uint32_t stop = depth == 0u ? end : (depth == 1u ? e0 : (depth == 2u ? e1 : e2));
-        const uint32_t scope = depth == 0u ? RT_NONE : (depth == 1u ? s0 : (depth == 2u ? s1 : s2));
-        bool enter = false;
-        RtNodeHot nd = ns.hot(n);
-        for (; n < stop; ++n) {
-            nd = ns.hot(n);
-            const bool active = (cur == n);
-            if (!RT_WAVE_ANY(active)) continue;
-            const uint32_t kind = nd.kind & RT_KIND_MASK;
-            if (kind >= RT_TRANSLATE && kind <= RT_FLIP) { enter = true; break; }
-            if (active) {
-                RT_STAT_VISIT(kind);
-                if (kind <= RT_BVH1) {
-                    bool hit;
-                    if (RT_WAVE_ANY(tmin_nan || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, cur_ray.o, inv, t_min, best_t);
-                    else hit = rt_aabb_hit_fast(nd.d, cur_ray.o, inv, t_min, best_t);
-                    cur = hit ? n + 1u : nd.skip;
-                } else if (kind <= RT_YZ) {
-                    double t;
-                    bool hit;
-                    if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[n], kind, cur_ray.o, cur_ray.d, world.time, t_min, best_t, t);
-                    else hit = rt_prim_hot_t(nd, kind, cur_ray.o, cur_ray.d, t_min, best_t, t);
-                    if (hit) { best_t = t; best_prim = n; best_scope = scope; }
-                    cur = n + 1u;
-                } else {
-                    if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
-                        const RtNode& full = nodes[n];
-                        RtRay br; br.o = cur_ray.o; br.d = cur_ray.d; br.time = world.time;
-                        double t1, t2, t; uint32_t p_, s_;
-                        if (rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, -RT_INF, RT_INF, rng, t1, p_, s_) &&
-                            rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, t1 + 0.0001, RT_INF, rng, t2, p_, s_) &&
-                            rt_medium_t(full, cur_ray.d, t1, t2, t_min, best_t, rng, t)) {
-                            best_t = t; best_prim = n; best_scope = scope;
-                        }
-                    }
-                    cur = nd.skip;
-                }
+    for (uint32_t n = root; n < end; ++n) {
+        const RtNodeHot nd = ns.hot(n);
+        /* lanes whose wrapper's subtree ended before n go back to the parent's ray */
+        if (RT_WAVE_ANY(scope_end <= n)) {
+            if (scope_end <= n) {
+                do {
+                    scope = nodes[scope].b;
+                    scope_end = (scope == RT_NONE) ? RT_NONE : nodes[scope].skip;
+                } while (scope_end <= n);
+                /* the parent's ray, recomputed from the outer ray by the operations that made it */
+                if (scope == RT_NONE) { cur_ray = w; inv = inv_w; }
+                else { cur_ray = rt_ray_in_scope(nodes, scope, w); inv = rt_inv3(cur_ray.d); }
             }
         }
-        if (enter) {
-            /* Translate::hit hittable.rs:207-211 / RotateY::hit :238-251 / FlipFace::hit :288-291 */
-            if (depth == 0u) { s0 = n; e0 = nd.skip; } else if (depth == 1u) { s1 = n; e1 = nd.skip; } else { s2 = n; e2 = nd.skip; }
-            ++depth;
-            cur_ray = rt_scope_in(nd, cur_ray);
-            if ((nd.kind & RT_KIND_MASK) == RT_ROTATE_Y) inv = rt_inv3(cur_ray.d);
-            cur = (cur == n) ? n + 1u : cur;
-            ++n;
-        } else if (depth != 0u) {
-            /* the subtree of the innermost wrapper ended: back to the parent's ray, recomputed from
-             * the outer ray by the operations that made it */
-            --depth;
-            if (depth == 0u) { cur_ray = w; inv = inv_w; }
-            else {
-                cur_ray = rt_scope_in(ns.hot(s0), w);
-                if (depth == 2u) cur_ray = rt_scope_in(ns.hot(s1), cur_ray);
-                inv = rt_inv3(cur_ray.d);
+        bool active = (cur == n);
+        if (!RT_WAVE_ANY(active)) continue;
+        const uint32_t kind = nd.kind & RT_KIND_MASK;
+        if (active) {
+            RT_STAT_VISIT(kind);
+            if (kind <= RT_BVH1) {
+                bool hit;
+                if (RT_WAVE_ANY(tmin_nan || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, cur_ray.o, inv, t_min, best_t);
+                else hit = rt_aabb_hit_fast(nd.d, cur_ray.o, inv, t_min, best_t);
+                cur = hit ? n + 1u : nd.skip;
+            } else if (kind <= RT_YZ) {
+                double t;
+                bool hit;
+                if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[n], kind, cur_ray.o, cur_ray.d, world.time, t_min, best_t, t);
+                else hit = rt_prim_hot_t(nd, kind, cur_ray.o, cur_ray.d, t_min, best_t, t);
+                if (hit) { best_t = t; best_prim = n; best_scope = scope; }
+                cur = n + 1u;
+            } else if (kind <= RT_FLIP) {
+                scope = n; scope_end = nd.skip;
+                if (kind == RT_TRANSLATE) {
+                    cur_ray.o = cur_ray.o - rt_v3(nd.d[0], nd.d[1], nd.d[2]);
+                } else if (kind == RT_ROTATE_Y) {
+                    double sn = nd.d[0], cs = nd.d[1];
+                    RtV3 o = cur_ray.o, d = cur_ray.d;
+                    cur_ray.o.x = cs * o.x - sn * o.z;
+                    cur_ray.o.z = sn * o.x + cs * o.z;
+                    cur_ray.d.x = cs * d.x - sn * d.z;
+                    cur_ray.d.z = sn * d.x + cs * d.z;
+                    inv = rt_inv3(cur_ray.d);
+                }
+                cur = n + 1u;
+            } else {
+                if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
+                    const RtNode& full = nodes[n];
+                    RtRay br; br.o = cur_ray.o; br.d = cur_ray.d; br.time = world.time;
+                    double t1, t2, t; uint32_t p_, s_;
+                    if (rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, -RT_INF, RT_INF, rng, t1, p_, s_) &&
+                        rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, t1 + 0.0001, RT_INF, rng, t2, p_, s_) &&
+                        rt_medium_t(full, cur_ray.d, t1, t2, t_min, best_t, rng, t)) {
+                        best_t = t; best_prim = n; best_scope = scope;
+                    }
+                }
+                cur = nd.skip;
             }
         }
     }
