@@ -39,6 +39,7 @@ extern "C" {
 #define RT1W_ERR_DEVICE (-3)      /* no GPU, HIP error */
 #define RT1W_ERR_NOMEM (-4)
 #define RT1W_ERR_STATE (-5)       /* e.g. mutate after commit, render before commit */
+#define RT1W_ERR_CANCELLED (-6)   /* the progress callback of rt1w_render_rows asked to stop */
 
 typedef struct rt1w_scene rt1w_scene;
 typedef struct rt1w_context rt1w_context;
@@ -182,6 +183,23 @@ int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out
  * order (top row = j = y0 + tile_h - 1 first, src/main.rs:957-960,1003-1007): out_rgb8[tile_h][tile_w][3].  No host
  * post-pass, 1/8 of the device->host bytes.   */
 int rt1w_render_u8(rt1w_context* c, const rt1w_render_params* p, uint8_t* out_rgb8, rt1w_stats* stats);
+
+/* Strip-wise render with progress, for big frames (C5 is 199 MB of f64 means).  The reference renders the rows top-down
+ * and reports progress as rows finish (src/main.rs:957-960 row order, :995-998 the stderr progress line).  This entry
+ * traces the tile in strips of `strip_rows` image rows from the top row (j = y0 + tile_h - 1) downwards; the finished strip
+ * is copied to the host on a second stream while the next one is traced, and `progress(user, rows_done, rows_total)` is
+ * called on the calling thread each time a strip has landed in `out` (rows_done counts from the top).  A non-zero return
+ * from the callback stops the render: strips already reported are valid, the call returns RT1W_ERR_CANCELLED.
+ *   format RT1W_ROWS_F64: out = double[tile_h][tile_w][3], the layout of rt1w_render (row 0 = j = y0);
+ *   format RT1W_ROWS_U8 : out = uint8_t[tile_h][tile_w][3], the layout of rt1w_render_u8 (top row first), so a PPM writer can
+ *                         stream rows out as they are reported.
+ * Every strip uses the sample-chunk size of the whole tile, so the result is bit-identical to rt1w_render / rt1w_render_u8.
+ * strip_rows = 0 picks about 16 strips, fewer when a strip would hold less than ~4M (pixel, sample-chunk) work items.  `progress` may be NULL.  stats (optional) are totals over the strips. */
+#define RT1W_ROWS_F64 0
+#define RT1W_ROWS_U8 1
+typedef int (*rt1w_progress_fn)(void* user, uint32_t rows_done, uint32_t rows_total);
+int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t strip_rows, int format, void* out,
+                     rt1w_progress_fn progress, void* user, rt1w_stats* stats);
 
 /* ---- output side (src/color.rs) ---- */
 

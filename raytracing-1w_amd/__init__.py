@@ -30,7 +30,8 @@ if not os.path.exists(LIB_PATH):
 _lib = C.CDLL(LIB_PATH)
 
 OK = 0
-ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_STATE = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_STATE, ERR_CANCELLED = -1, -2, -3, -4, -5, -6
+ROWS_F64, ROWS_U8 = 0, 1
 OUT_SUM = 1
 UNSORTED = 2
 LDS_NODES = 4
@@ -114,6 +115,8 @@ _sig("rt1w_default_chunk", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("rt1w_render", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_u8", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, _P, C.c_uint32, C.c_uint32)
+_sig("rt1w_render_rows", C.c_int, _P, C.POINTER(RenderParams), C.c_uint32, C.c_int, _P, PROGRESS_FN, _P, C.POINTER(Stats))
 _sig("rt1w_resolve", C.c_int, _P, C.c_uint64, C.c_uint32, _P)
 _sig("rt1w_quantize", C.c_int, _P, C.c_uint64, _P)
 _sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
@@ -318,6 +321,21 @@ class Context:
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.uint8)
         st = Stats()
         _ck(_lib.rt1w_render_u8(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
+        return out, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def render_rows(self, width, height, spp, strip_rows=0, u8=False, progress=None, max_depth=50, tile=None,
+                    sample_offset=0, global_seed=0, chunk=0, out_sum=False, out=None):
+        """Strip-wise render from the top row down with D2H overlapped (rt1w_render_rows).  `progress(rows_done, rows_total)`
+        is called as strips land; returning a true value cancels (raises Rt1wError with code ERR_CANCELLED).
+        Returns the same arrays as render() (u8=False) or render_u8() (u8=True)."""
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum)
+        if out is None:
+            out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.uint8 if u8 else np.float64)
+        assert out.flags.c_contiguous and out.shape == (p.tile_h, p.tile_w, 3) and out.dtype == (np.uint8 if u8 else np.float64)
+        st = Stats()
+        cb = PROGRESS_FN((lambda user, done, total: 1 if progress(done, total) else 0) if progress else 0)
+        _ck(_lib.rt1w_render_rows(self._h, C.byref(p), strip_rows, ROWS_U8 if u8 else ROWS_F64, out.ctypes.data_as(_P), cb,
+                                  None, C.byref(st)))
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
     def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0,

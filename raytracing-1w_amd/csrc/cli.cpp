@@ -70,18 +70,33 @@ int main(int argc, char** argv) {
     std::memset(&p, 0, sizeof p);
     p.width = (uint32_t)width; p.height = (uint32_t)height; p.tile_w = p.width; p.tile_h = p.height;
     p.spp = (uint32_t)spp; p.max_depth = (uint32_t)depth; p.global_seed = (uint32_t)seed;
-    std::vector<double> img((size_t)width * height * 3);
-    rt1w_stats st;
-    std::fprintf(stderr, "rt1w: scene arm %d, %ldx%ld, %ld spp, depth %ld\n", arm, width, height, spp, depth);
-    if (rt1w_render(ctx, &p, img.data(), &st) < 0) return fail("render");
-    std::fprintf(stderr, "rt1w: %.1f ms kernel, %.1f Mpaths/s, %.2f segments/path, kernel variant V%u\nDone\n", st.kernel_ms,
-                 (double)st.paths / st.kernel_ms / 1e3, (double)st.segments / (double)st.paths, st.variant);
-    int64_t n = rt1w_format_ppm(img.data(), p.width, p.height, nullptr, 0);
-    std::vector<char> txt((size_t)n + 1);
-    if (rt1w_format_ppm(img.data(), p.width, p.height, txt.data(), (uint64_t)n + 1) < 0) return fail("ppm");
+    /* the reference collects the rows top-down, counting them down on stderr (main.rs:957-960,995-998), then prints them
+     * (main.rs:1003-1007); here the rows are quantised on the device and written as their strips land */
+    std::vector<unsigned char> img((size_t)width * height * 3);
     FILE* o = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "w");
     if (!o) { std::perror("rt1w: --out"); return 1; }
-    std::fwrite(txt.data(), 1, (size_t)n, o);
+    std::fprintf(o, "P3\n%u %u\n255\n", p.width, p.height);
+    struct Sink { FILE* o; const unsigned char* img; uint32_t w, written; std::string line; } sink{o, img.data(), p.width, 0, {}};
+    auto on_rows = [](void* user, uint32_t rows_done, uint32_t rows_total) -> int {
+        Sink& k = *static_cast<Sink*>(user);
+        for (; k.written < rows_done; ++k.written) {
+            const unsigned char* row = k.img + (size_t)k.written * k.w * 3;
+            k.line.clear();
+            char buf[16];
+            for (uint32_t i = 0; i < k.w; ++i) {
+                int n = std::snprintf(buf, sizeof buf, "%u %u %u\n", row[3 * i], row[3 * i + 1], row[3 * i + 2]); /* color.rs:59-64 */
+                k.line.append(buf, (size_t)n);
+            }
+            std::fwrite(k.line.data(), 1, k.line.size(), k.o);
+        }
+        std::fprintf(stderr, "\rScanlines remaining: %u ", rows_total - rows_done);
+        return 0;
+    };
+    rt1w_stats st;
+    std::fprintf(stderr, "rt1w: scene arm %d, %ldx%ld, %ld spp, depth %ld\n", arm, width, height, spp, depth);
+    if (rt1w_render_rows(ctx, &p, 0, RT1W_ROWS_U8, img.data(), on_rows, &sink, &st) < 0) return fail("render");
+    std::fprintf(stderr, "\nDone\nrt1w: %.1f ms kernels, %.1f Mpaths/s, %.2f segments/path, kernel variant V%u\n", st.kernel_ms,
+                 (double)st.paths / st.kernel_ms / 1e3, (double)st.segments / (double)st.paths, st.variant);
     if (o != stdout) std::fclose(o);
     rt1w_context_destroy(ctx);
     rt1w_scene_destroy(scene);

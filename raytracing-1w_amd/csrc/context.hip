@@ -416,16 +416,26 @@ bool hip_ok(hipError_t e, const char* what) {
 
 } // namespace
 
-struct rt1w_context {
-    int device = 0;
+/* Everything one in-flight render needs.  Lane 0 serves the one-shot entries; rt1w_render_rows keeps two strips in
+ * flight, one per lane, so that the next strip's workgroups fill the CUs as the previous strip's persistent kernel tails off
+ * and its device->host copy runs under the other lane's tracing. */
+struct RtLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* d_partial = nullptr; size_t partial_bytes = 0;
+    unsigned long long* d_counters = nullptr;
+    unsigned long long* h_counters = nullptr; /* pinned */
+    void* d_strip = nullptr; void* h_strip = nullptr; size_t strip_bytes = 0; /* rt1w_render_rows: device strip + pinned host strip */
+};
+
+struct rt1w_context {
+    int device = 0;
+    RtLane lane[2];
+    hipEvent_t ev_first = nullptr;
     void* d_nodes = nullptr; void* d_lights = nullptr; void* d_materials = nullptr;
     void* d_textures = nullptr; void* d_perlin = nullptr; void* d_images = nullptr;
     RtSceneView view{};
-    double* d_partial = nullptr; size_t partial_bytes = 0;
     double* d_out = nullptr; size_t out_bytes = 0;
-    unsigned long long* d_counters = nullptr;
     int grid[RT_N_VARIANTS] = {0, 0, 0, 0};
     int grid_sorted[RT_N_VARIANTS] = {0, 0, 0, 0};
     int grid_cached[RT_N_VARIANTS] = {0, 0, 0, 0};
@@ -465,8 +475,34 @@ int validate(const rt1w_context* c, const rt1w_render_params* p) {
     return RT1W_OK;
 }
 
-int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, rt1w_stats* stats) {
-    RtFrame f;
+__global__ void rt_init_counters_kernel(unsigned long long* ctr, unsigned long long next_item) { ctr[0] = next_item; ctr[1] = 0ull; }
+
+bool lane_init(RtLane& l) {
+    if (l.stream) return true;
+    /* ordinary (blocking) streams: ordered after work the caller queued on the null stream, e.g. on the tensor handed to
+     * rt1w_render_device; the two lanes still run concurrently with each other */
+    return hip_ok(hipStreamCreate(&l.stream), "hipStreamCreate") &&
+           hip_ok(hipEventCreate(&l.ev0), "hipEventCreate") && hip_ok(hipEventCreate(&l.ev1), "hipEventCreate") &&
+           hip_ok(hipMalloc((void**)&l.d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(counters)") &&
+           hip_ok(hipHostMalloc((void**)&l.h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(counters)");
+}
+void lane_destroy(RtLane& l) {
+    if (l.d_partial) (void)hipFree(l.d_partial);
+    if (l.d_counters) (void)hipFree(l.d_counters);
+    if (l.h_counters) (void)hipHostFree(l.h_counters);
+    if (l.d_strip) (void)hipFree(l.d_strip);
+    if (l.h_strip) (void)hipHostFree(l.h_strip);
+    if (l.ev0) (void)hipEventDestroy(l.ev0);
+    if (l.ev1) (void)hipEventDestroy(l.ev1);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+    l = RtLane();
+}
+
+struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached; };
+
+/* what the launch will need, without launching: frame, variant, launch shape */
+int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
+    RtFrame& f = L.f;
     f.width = p->width; f.height = p->height;
     f.x0 = p->x0; f.y0 = p->y0; f.tile_w = p->tile_w; f.tile_h = p->tile_h;
     f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth;
@@ -474,14 +510,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
     f.chunk = p->chunk ? p->chunk : rt1w_default_chunk(p->tile_w, p->tile_h, p->spp);
     if (f.chunk > f.spp) f.chunk = f.spp;
     f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
-    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
-    size_t need = (size_t)npix * f.n_chunks * 3 * sizeof(double);
-    if (need > c->partial_bytes) {
-        if (c->d_partial) (void)hipFree(c->d_partial);
-        c->d_partial = nullptr; c->partial_bytes = 0;
-        if (!hip_ok(hipMalloc((void**)&c->d_partial, need), "hipMalloc(partial sums)")) return RT1W_ERR_NOMEM;
-        c->partial_bytes = need;
-    }
+    L.npix = (unsigned long long)f.tile_w * f.tile_h;
     int variant = c->variant;
     if (p->flags >> 8) {
         variant = (int)((p->flags >> 8) & 0xFFu) - 1;
@@ -489,38 +518,67 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
             rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
         }
     }
-    const bool sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
-    const bool cached = !sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
-    const int grid = sorted ? c->grid_sorted[variant] : (cached ? c->grid_cached[variant] : c->grid[variant]);
-    const int block = sorted ? RT_SORT_BLOCK : RT_BLOCK;
-    unsigned long long init[2] = {(unsigned long long)grid * block, 0ull};
-    if (!hip_ok(hipMemcpyAsync(c->d_counters, init, sizeof init, hipMemcpyHostToDevice, c->stream), "counter init")) return RT1W_ERR_DEVICE;
-    if (!hip_ok(hipStreamSynchronize(c->stream), "counter init sync")) return RT1W_ERR_DEVICE;
-    (void)hipEventRecord(c->ev0, c->stream);
-    hipLaunchKernelGGL(sorted ? g_kernels_sorted[variant] : (cached ? g_kernels_cached[variant] : g_kernels[variant]), dim3(grid), dim3(block), 0, c->stream, c->view, f,
-                       c->d_partial, c->d_counters);
-    {
-        unsigned int rb = 256;
-        unsigned int rg = (unsigned int)((npix + rb - 1) / rb);
-        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, c->stream, c->d_partial, d_out, npix, f.n_chunks,
-                           f.spp, (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
-    }
-    (void)hipEventRecord(c->ev1, c->stream);
-    if (!hip_ok(hipGetLastError(), "kernel launch")) return RT1W_ERR_DEVICE;
-    if (!hip_ok(hipStreamSynchronize(c->stream), "render kernel")) return RT1W_ERR_DEVICE;
-    if (stats) {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        unsigned long long cnt[2] = {0, 0};
-        (void)hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost);
-        stats->paths = npix * f.spp;
-        stats->segments = cnt[1];
-        stats->kernel_ms = ms;
-        stats->chunk = f.chunk; stats->n_chunks = f.n_chunks;
-        stats->grid = (uint32_t)grid; stats->block = (uint32_t)block;
-        stats->variant = (uint32_t)variant; stats->sorted = (sorted ? 1u : 0u) | (cached ? 2u : 0u);
+    L.variant = variant;
+    L.sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
+    L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
+    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : c->grid[variant]);
+    L.block = L.sorted ? RT_SORT_BLOCK : RT_BLOCK;
+    return RT1W_OK;
+}
+
+int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
+    size_t need = (size_t)L.npix * L.f.n_chunks * 3 * sizeof(double);
+    if (need > l.partial_bytes) {
+        if (l.d_partial) (void)hipFree(l.d_partial);
+        l.d_partial = nullptr; l.partial_bytes = 0;
+        if (!hip_ok(hipMalloc((void**)&l.d_partial, need), "hipMalloc(partial sums)")) return RT1W_ERR_NOMEM;
+        l.partial_bytes = need;
     }
     return RT1W_OK;
+}
+
+/* enqueue on the lane's stream: counters, trace kernel, resolve into d_out, counters back to pinned memory.  No host wait. */
+int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const RtLaunch& L, double* d_out) {
+    hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block);
+    (void)hipEventRecord(l.ev0, l.stream);
+    hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : g_kernels[L.variant]),
+                       dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
+    {
+        unsigned int rb = 256;
+        unsigned int rg = (unsigned int)((L.npix + rb - 1) / rb);
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, L.npix, L.f.n_chunks,
+                           L.f.spp, (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
+    }
+    (void)hipEventRecord(l.ev1, l.stream);
+    if (!hip_ok(hipGetLastError(), "kernel launch")) return RT1W_ERR_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(l.h_counters, l.d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream), "counter copy")) return RT1W_ERR_DEVICE;
+    return RT1W_OK;
+}
+
+/* wait for everything enqueued on the lane and fill the stats of its last launch */
+int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
+    if (!hip_ok(hipStreamSynchronize(l.stream), "render kernel")) return RT1W_ERR_DEVICE;
+    if (stats) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, l.ev0, l.ev1);
+        stats->paths = L.npix * L.f.spp;
+        stats->segments = l.h_counters[1];
+        stats->kernel_ms = ms;
+        stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
+        stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
+        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u);
+    }
+    return RT1W_OK;
+}
+
+int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, rt1w_stats* stats) {
+    RtLaunch L;
+    int rc = render_plan(c, p, L);
+    if (rc < 0) return rc;
+    RtLane& l = c->lane[0];
+    if ((rc = lane_reserve_partial(l, L)) < 0) return rc;
+    if ((rc = render_launch(c, l, p, L, d_out)) < 0) return rc;
+    return render_finish(l, L, stats);
 }
 
 } // namespace
@@ -528,12 +586,18 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
 extern "C" {
 
 uint32_t rt1w_default_chunk(uint32_t tile_w, uint32_t tile_h, uint32_t spp) {
-    /* aim for >= ~4M work items so that every resident lane gets >= 16 of them
-     * (tail of the persistent loop ~ 1/32 of the run), but never split below 8 samples */
-    const uint64_t target_items = 4u << 20;
+    /* Work item = (pixel, chunk of samples).  The persistent kernel's tail is about half an item long, so:
+     *  - aim for >= ~16M items (>= 80 per resident lane; measured on C3: 4M items 1764, 16M items 1790 Mpaths/s),
+     *  - never more than 512 samples in an item (big frames at 10k spp: a whole pixel would be seconds of tail),
+     *  - never split below 8 samples, and keep the chunk partial sums (24 B per item) under 8 GiB. */
+    const uint64_t target_items = 16u << 20;
     uint64_t pixels = (uint64_t)tile_w * tile_h;
     if (pixels == 0 || spp == 0) return 1;
     uint64_t n_chunks = (target_items + pixels - 1) / pixels;
+    const uint64_t by_len = ((uint64_t)spp + 511u) / 512u;
+    if (n_chunks < by_len) n_chunks = by_len;
+    const uint64_t by_mem = ((8ull << 30) / 24u) / pixels;
+    if (n_chunks > by_mem) n_chunks = by_mem;
     if (n_chunks < 1) n_chunks = 1;
     if (n_chunks > spp) n_chunks = spp;
     uint32_t chunk = (uint32_t)((spp + n_chunks - 1) / n_chunks);
@@ -559,15 +623,13 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     rt1w_context* c = new (std::nothrow) rt1w_context();
     if (!c) { rt1w::set_error("out of memory"); return RT1W_ERR_NOMEM; }
     c->device = device_id;
-    bool ok = hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") && hip_ok(hipEventCreate(&c->ev0), "hipEventCreate") &&
-              hip_ok(hipEventCreate(&c->ev1), "hipEventCreate") &&
+    bool ok = lane_init(c->lane[0]) &&
               upload(&c->d_nodes, s->flat_nodes.data(), s->flat_nodes.size() * sizeof(RtNode)) &&
               upload(&c->d_lights, s->flat_lights.data(), s->flat_lights.size() * sizeof(RtNode)) &&
               upload(&c->d_materials, s->materials.data(), s->materials.size() * sizeof(RtMaterial)) &&
               upload(&c->d_textures, s->textures.data(), s->textures.size() * sizeof(RtTexture)) &&
               upload(&c->d_perlin, s->perlin.data(), s->perlin.size() * sizeof(RtPerlin)) &&
-              upload(&c->d_images, s->images.data(), s->images.size()) &&
-              hip_ok(hipMalloc((void**)&c->d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(counters)");
+              upload(&c->d_images, s->images.data(), s->images.size());
     if (!ok) { rt1w_context_destroy(c); return RT1W_ERR_DEVICE; }
     RtSceneView& v = c->view;
     v.nodes = (const RtNode*)c->d_nodes; v.lights = (const RtNode*)c->d_lights;
@@ -614,12 +676,11 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
 void rt1w_context_destroy(rt1w_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images,
-                    c->d_partial, c->d_out, c->d_counters};
+    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images, c->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    lane_destroy(c->lane[0]);
+    lane_destroy(c->lane[1]);
+    if (c->ev_first) (void)hipEventDestroy(c->ev_first);
     delete c;
 }
 
@@ -652,10 +713,120 @@ int rt1w_render_u8(rt1w_context* c, const rt1w_render_params* p, uint8_t* out_rg
     rc = render_common(c, p, c->d_out, stats);
     if (rc < 0) return rc;
     uint8_t* d_u8 = reinterpret_cast<uint8_t*>(c->d_out + npix * 3);
-    hipLaunchKernelGGL(rt_quantize_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, c->d_out, d_u8, p->tile_w, p->tile_h);
-    if (!hip_ok(hipMemcpyAsync(out_rgb8, d_u8, npix * 3, hipMemcpyDeviceToHost, c->stream), "quantised image copy") ||
-        !hip_ok(hipStreamSynchronize(c->stream), "quantise kernel")) return RT1W_ERR_DEVICE;
+    hipLaunchKernelGGL(rt_quantize_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->lane[0].stream, c->d_out, d_u8, p->tile_w, p->tile_h);
+    if (!hip_ok(hipMemcpyAsync(out_rgb8, d_u8, npix * 3, hipMemcpyDeviceToHost, c->lane[0].stream), "quantised image copy") ||
+        !hip_ok(hipStreamSynchronize(c->lane[0].stream), "quantise kernel")) return RT1W_ERR_DEVICE;
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT1W_OK;
+}
+
+int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t strip_rows, int format, void* out,
+                     rt1w_progress_fn progress, void* user, rt1w_stats* stats) {
+    int rc = validate(c, p);
+    if (rc < 0) return rc;
+    if (!out) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
+    if (format != RT1W_ROWS_F64 && format != RT1W_ROWS_U8) { rt1w::set_error("unknown output format"); return RT1W_ERR_INVALID; }
+    if (format == RT1W_ROWS_U8 && (p->flags & RT1W_OUT_SUM)) { rt1w::set_error("RT1W_OUT_SUM has no 8-bit form"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t H = p->tile_h, W = p->tile_w;
+    const uint32_t tile_chunk = p->chunk ? p->chunk : rt1w_default_chunk(W, H, p->spp); /* the whole tile's chunking */
+    if (strip_rows == 0) {
+        /* about 16 strips, but never so thin that a strip has fewer than ~4M work items (pixel x sample chunk): the
+         * persistent kernel needs that many to keep its tail short, and the chunking is the whole tile's by contract */
+        const uint64_t n_chunks = (p->spp + (uint64_t)(tile_chunk < p->spp ? tile_chunk : p->spp) - 1u) / (tile_chunk < p->spp ? tile_chunk : p->spp);
+        const uint64_t min_rows = ((4ull << 20) + (uint64_t)W * n_chunks - 1u) / ((uint64_t)W * n_chunks);
+        uint64_t rows = (H + 15u) / 16u;
+        if (rows < min_rows) rows = min_rows;
+        rows = (rows + 7u) & ~7ull;
+        strip_rows = rows > H ? H : (uint32_t)rows;
+    }
+    if (strip_rows > H) strip_rows = H;
+    /* one strip: f64 means, and behind them the quantised bytes when asked for */
+    const size_t strip_px = (size_t)strip_rows * W;
+    const size_t f64_bytes = strip_px * 3 * sizeof(double);
+    const size_t dev_bytes = f64_bytes + (format == RT1W_ROWS_U8 ? strip_px * 3 : 0);
+    rt1w_render_params sp = *p;
+    sp.chunk = tile_chunk; /* same sums, same bits */
+    sp.tile_h = strip_rows;
+    RtLaunch plan;
+    if ((rc = render_plan(c, &sp, plan)) < 0) return rc;
+    /* all allocation up front: hipMalloc/hipFree in the loop would serialise the two lanes */
+    if (!c->ev_first && !hip_ok(hipEventCreate(&c->ev_first), "hipEventCreate")) return RT1W_ERR_DEVICE;
+    for (int k = 0; k < 2; ++k) {
+        RtLane& l = c->lane[k];
+        if (!lane_init(l)) return RT1W_ERR_DEVICE;
+        if ((rc = lane_reserve_partial(l, plan)) < 0) return rc;
+        if (dev_bytes > l.strip_bytes) {
+            if (l.d_strip) (void)hipFree(l.d_strip);
+            if (l.h_strip) (void)hipHostFree(l.h_strip);
+            l.d_strip = l.h_strip = nullptr; l.strip_bytes = 0;
+            if (!hip_ok(hipMalloc(&l.d_strip, dev_bytes), "hipMalloc(strip)") ||
+                !hip_ok(hipHostMalloc(&l.h_strip, dev_bytes, hipHostMallocDefault), "hipHostMalloc(strip)")) return RT1W_ERR_NOMEM;
+            l.strip_bytes = dev_bytes;
+        }
+    }
+    const uint32_t n_strips = (H + strip_rows - 1u) / strip_rows;
+    struct Flight { RtLaunch L; uint32_t top, rows; } fl[2];
+    rt1w_stats total; memset(&total, 0, sizeof total);
+    uint32_t rows_done = 0;
+    /* strip i goes to lane i & 1: trace, resolve, (quantise,) copy to the lane's pinned strip -- all on the lane's stream */
+    auto launch = [&](uint32_t i) -> int {
+        RtLane& l = c->lane[i & 1u];
+        Flight& F = fl[i & 1u];
+        F.top = i * strip_rows;
+        F.rows = (H - F.top < strip_rows) ? H - F.top : strip_rows;
+        sp.tile_h = F.rows;
+        sp.y0 = p->y0 + (H - F.top - F.rows);
+        int r = render_plan(c, &sp, F.L);
+        if (r < 0) return r;
+        if (i == 0) (void)hipEventRecord(c->ev_first, l.stream);
+        if ((r = render_launch(c, l, &sp, F.L, (double*)l.d_strip)) < 0) return r;
+        const uint8_t* src = (const uint8_t*)l.d_strip;
+        const size_t npix = (size_t)F.rows * W;
+        if (format == RT1W_ROWS_U8) {
+            uint8_t* d_u8 = (uint8_t*)l.d_strip + f64_bytes;
+            hipLaunchKernelGGL(rt_quantize_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, l.stream,
+                               (const double*)l.d_strip, d_u8, W, F.rows);
+            src = d_u8;
+        }
+        const size_t nbytes = format == RT1W_ROWS_U8 ? npix * 3 : npix * 3 * sizeof(double);
+        if (!hip_ok(hipMemcpyAsync(l.h_strip, src, nbytes, hipMemcpyDeviceToHost, l.stream), "strip copy")) return RT1W_ERR_DEVICE;
+        return RT1W_OK;
+    };
+    /* waits for strip i, lands it in the caller's buffer and reports it; > 0 = the callback asked to stop */
+    auto land = [&](uint32_t i) -> int {
+        RtLane& l = c->lane[i & 1u];
+        Flight& F = fl[i & 1u];
+        rt1w_stats st;
+        int r = render_finish(l, F.L, &st);
+        if (r < 0) return r;
+        total.paths += st.paths; total.segments += st.segments;
+        total.chunk = st.chunk; total.n_chunks = st.n_chunks; total.grid = st.grid; total.block = st.block;
+        total.variant = st.variant; total.sorted = st.sorted;
+        if (i + 1u == n_strips) { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev_first, l.ev1); total.kernel_ms = ms; }
+        if (format == RT1W_ROWS_U8) memcpy((uint8_t*)out + (size_t)F.top * W * 3, l.h_strip, (size_t)F.rows * W * 3);
+        else memcpy((double*)out + (size_t)(H - F.top - F.rows) * W * 3, l.h_strip, (size_t)F.rows * W * 3 * sizeof(double));
+        rows_done += F.rows;
+        return (progress && progress(user, rows_done, H) != 0) ? 1 : 0;
+    };
+    if ((rc = launch(0)) < 0) return rc;
+    for (uint32_t i = 0; i < n_strips; ++i) {
+        if (i + 1u < n_strips && (rc = launch(i + 1u)) < 0) { (void)hipStreamSynchronize(c->lane[i & 1u].stream); return rc; }
+        rc = land(i);
+        if (rc != 0) {
+            /* error or cancel: the strip already in flight on the other lane is left to finish, unreported */
+            if (i + 1u < n_strips) (void)hipStreamSynchronize(c->lane[(i + 1u) & 1u].stream);
+            if (rc < 0) return rc;
+            if (i + 1u == n_strips) break; /* asked to stop after the last strip: nothing left to stop */
+            rt1w::set_error("cancelled by the progress callback");
+            return RT1W_ERR_CANCELLED;
+        }
+    }
+    if (stats) {
+        *stats = total; /* kernel_ms: first strip's start to last strip's end on the device (the strips overlap) */
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     return RT1W_OK;
 }
 
@@ -689,8 +860,8 @@ int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* ou
         !hip_ok(hipMalloc((void**)&d1, n * sizeof(int)), "hipMalloc")) rc = RT1W_ERR_NOMEM;
     if (rc == RT1W_OK) {
         (void)hipMemcpy(din, in, n * 14 * sizeof(double), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(rt_debug_aabb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, din, d0, d1, (unsigned long long)n);
-        if (!hip_ok(hipStreamSynchronize(c->stream), "debug kernel")) rc = RT1W_ERR_DEVICE;
+        hipLaunchKernelGGL(rt_debug_aabb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->lane[0].stream, din, d0, d1, (unsigned long long)n);
+        if (!hip_ok(hipStreamSynchronize(c->lane[0].stream), "debug kernel")) rc = RT1W_ERR_DEVICE;
         else { (void)hipMemcpy(out_literal, d0, n * sizeof(int), hipMemcpyDeviceToHost); (void)hipMemcpy(out_fast, d1, n * sizeof(int), hipMemcpyDeviceToHost); }
     }
     if (din) (void)hipFree(din);
@@ -727,8 +898,8 @@ int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, d
     if (rc == RT1W_OK) {
         (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
         (void)hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(rt_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fn, da, db, dout, (unsigned long long)n);
-        if (!hip_ok(hipStreamSynchronize(c->stream), "debug kernel")) rc = RT1W_ERR_DEVICE;
+        hipLaunchKernelGGL(rt_debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->lane[0].stream, fn, da, db, dout, (unsigned long long)n);
+        if (!hip_ok(hipStreamSynchronize(c->lane[0].stream), "debug kernel")) rc = RT1W_ERR_DEVICE;
         else (void)hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
     }
     if (da) (void)hipFree(da);

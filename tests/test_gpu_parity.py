@@ -346,3 +346,42 @@ def test_device_side_quantiser_matches_host(rt, gpu_ctx_factory):
     u8, _ = ctx.render_u8(40, 30, 4)
     txt = "P3\n40 30\n255\n" + "".join("%d %d %d\n" % tuple(px) for row in u8 for px in row)
     assert txt == rt.format_ppm(img)
+
+
+def test_strip_render_with_progress_is_bit_identical(rt, gpu_ctx_factory):
+    """rt1w_render_rows (main.rs:957-960 row order, :995-998 progress): strips from the top row down,
+    D2H overlapped; same bits as the one-shot entries for every strip size, on a whole frame, a ragged last strip and a
+    sub-tile; progress is monotonic and ends at tile_h; a true return cancels with the rows reported so far intact."""
+    ctx = gpu_ctx_factory(rt.Scene.reference(5, build_seed=1))
+    for (W, H, spp, tile, strip) in ((96, 80, 24, None, 0), (96, 80, 24, None, 7), (96, 80, 24, None, 80), (96, 80, 24, None, 500),
+                                     (64, 64, 5, (3, 11, 40, 33), 8), (32, 24, 70, None, 1)):
+        ref, s0 = ctx.render(W, H, spp, tile=tile)
+        ref8, _ = ctx.render_u8(W, H, spp, tile=tile)
+        seen = []
+        img, s1 = ctx.render_rows(W, H, spp, strip_rows=strip, tile=tile, progress=lambda d, t: seen.append((d, t)) or 0)
+        th = ref.shape[0]
+        assert np.array_equal(img, ref, equal_nan=True)
+        assert s1["paths"] == s0["paths"] and s1["segments"] == s0["segments"]
+        assert seen and seen[-1] == (th, th) and all(t == th for _, t in seen)
+        assert [d for d, _ in seen] == sorted(set(d for d, _ in seen))
+        if strip not in (0,) and strip < th:
+            assert [d for d, _ in seen][0] == strip
+        u8, _ = ctx.render_rows(W, H, spp, strip_rows=strip, tile=tile, u8=True)
+        assert u8.dtype == np.uint8 and np.array_equal(u8, ref8)
+    # raw sums (multi-rank sample ranges) come through as well
+    a, _ = ctx.render(48, 40, 6, out_sum=True, sample_offset=3)
+    b, _ = ctx.render_rows(48, 40, 6, strip_rows=16, out_sum=True, sample_offset=3)
+    assert np.array_equal(a, b, equal_nan=True)
+    # cancel after the second strip: rows reported so far are final, the call says so
+    ref8, _ = ctx.render_u8(64, 64, 8)
+    calls = []
+    out = np.full((64, 64, 3), 7, dtype=np.uint8)
+    with pytest.raises(rt.Rt1wError) as e:
+        ctx.render_rows(64, 64, 8, strip_rows=8, u8=True, progress=lambda d, t: calls.append(d) or d >= 16, out=out)
+    assert e.value.code == rt.ERR_CANCELLED and calls == [8, 16]
+    assert np.array_equal(out[:16], ref8[:16]) and np.all(out[16:] == 7)
+    # the context is still usable
+    again, _ = ctx.render_rows(64, 64, 8, strip_rows=8, u8=True)
+    assert np.array_equal(again, ref8)
+    with pytest.raises(rt.Rt1wError):
+        ctx.render_rows(64, 64, 8, u8=True, out_sum=True)
