@@ -14,8 +14,8 @@
  * vectors or fixtures.  What pins this oracle instead:
  *   (1) line-by-line correspondence with the cited source;
  *   (2) hand-derived known answers for the leaf functions (tests/test_oracle_kat.py);
- *   (3) a statistical match of the Cornell render against the only artefact of
- *       the reference's own run, rest_of_your_life.png (tests/golden/);
+ *   (3) statistical matches against the artefacts of the reference's own runs: the Cornell render against
+ *       rest_of_your_life.png, the final_scene render against the comparable blocks of next_week.png (tests/golden/);
  *   (4) Random123 known-answer vectors for the generator.
  *
  * Deliberate, documented departures from the Rust (all mandated by the north

@@ -1,7 +1,8 @@
 """Generates the committed golden fixtures.  Run in the build container only:
     python tests/golden/make_golden.py
-(1) block means of the reference's own artefact rest_of_your_life.png (read from
-    /root/reference -- the only output of the reference's own run that exists);
+(1) block means of the reference's own artefacts rest_of_your_life.png (Cornell, master) and next_week.png
+    (final_scene, an earlier revision) read from /root/reference -- the only outputs of the reference's own runs
+    that match a scene arm of master (one_weekend.png is the book-1 scene: gradient sky, no checker, no motion blur);
 (2) golden framebuffers of the literal CPU oracle (oracle/oracle.cpp) for small
     configurations of every scene arm, incl. BASELINE config C1 (Cornell 200x200x64).
 The reference (Rust) cannot be run here, so (2) are oracle outputs, not reference
@@ -21,6 +22,22 @@ def png_blocks():
     return {"source": "rest_of_your_life.png (hatoo/raytracing-1w master, README.md:19)", "shape": [600, 600],
             "block": 100, "channel_means": im.mean(axis=(0, 1)).tolist(), "block_means_top_down": b.tolist()}
 
+def png_blocks_final():
+    """next_week.png = the reference's own render of the final_scene arm (README.md:15), made by an EARLIER revision:
+    its light emits from both faces (master: front face only, material.rs:168-181 + FlipFace, main.rs:655-662), so the
+    fog-lit region above the light plane (image rows 0-1) is brighter than master's, and the ground boxes / the cube of
+    small spheres are placed by thread_rng.  Pinned here: the blocks below the light plane that hold neither saturated
+    pixels nor randomly placed geometry -- linear means (the PNG's 8-bit gamma values mapped back through color.rs:56-65)."""
+    from PIL import Image
+    im = np.asarray(Image.open('/root/reference/next_week.png').convert('RGB'), dtype=np.float64)
+    assert im.shape == (800, 800, 3)
+    lin = ((im + 0.5) / 256.0) ** 2
+    b = lin.reshape(8, 100, 8, 100, 3).mean(axis=(1, 3))
+    sel = [(2, 0), (2, 1), (2, 2), (2, 3), (2, 5), (2, 6), (2, 7), (3, 0), (3, 1), (3, 2), (3, 3), (3, 6), (3, 7),
+           (4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (4, 6), (4, 7)]
+    return {"source": "next_week.png (hatoo/raytracing-1w, README.md:15; rendered by an earlier revision, see make_golden.py)",
+            "shape": [800, 800], "block": 100, "linear_block_means_top_down": b.tolist(), "selected_blocks": sel}
+
 CASES = {  # name: (arm, W, H, spp, depth)
     "c1_cornell_200x200x64": (5, 200, 200, 64, 50),
     "random_scene_96x64x8": (0, 96, 64, 8, 50),
@@ -36,6 +53,8 @@ CASES = {  # name: (arm, W, H, spp, depth)
 def main():
     with open(os.path.join(HERE, 'cornell_png_blocks.json'), 'w') as f:
         json.dump(png_blocks(), f, indent=1)
+    with open(os.path.join(HERE, 'final_scene_png_blocks.json'), 'w') as f:
+        json.dump(png_blocks_final(), f, indent=1)
     meta = {}
     arrays = {}
     for name, (arm, W, H, spp, depth) in CASES.items():
