@@ -141,6 +141,7 @@ void rt1w_context_destroy(rt1w_context* c);
 
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
+#define RT1W_GENERIC 8u   /* do not use a scene-specialised kernel even if the context has one (rt1w_context_specialise) */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering) */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
@@ -200,6 +201,26 @@ int rt1w_render_u8(rt1w_context* c, const rt1w_render_params* p, uint8_t* out_rg
 typedef int (*rt1w_progress_fn)(void* user, uint32_t rows_done, uint32_t rows_total);
 int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t strip_rows, int format, void* out,
                      rt1w_progress_fn progress, void* user, rt1w_stats* stats);
+
+/* ---- scene-specialised kernels ----
+ * Scenes of up to 64 flattened nodes (Cornell: 29) are traversed by a stackless pre-order sweep.  When the node kinds
+ * and subtree ends are compile-time constants that sweep unrolls into straight-line code along the scene's own tree
+ * (about 15 % faster on the Cornell box; same arithmetic, bit-identical frames).  The constants are only known once a
+ * scene is committed, so such a kernel is generated per scene topology and compiled with hiprtc (3-5 s), then kept in a
+ * kernel cache: <directory of librt1w.so>/kernels (filled by the build for the reference's own scene arms) and
+ * $RT1W_KERNEL_CACHE or ~/.cache/rt1w.  rt1w_context_create looks the scene up in the cache and uses a hit silently;
+ * rt1w_context_specialise compiles on a miss.  A render of >= 2^35 paths compiles on its own (the compile then costs
+ * less than it saves) unless RT1W_NO_JIT is set in the environment.  Larger scenes keep the generic kernels:
+ * RT1W_ERR_UNSUPPORTED.  RT1W_GENERIC in rt1w_render_params.flags selects the generic kernel for one render. */
+#define RT1W_SPECIALISE_CACHED_ONLY 1u /* do not run the compiler: RT1W_ERR_STATE on a cache miss */
+typedef struct rt1w_specialise_info {
+    char key[24];        /* cache key: hash of the generated source, the library's embedded headers and the compiler options */
+    uint32_t active;     /* 1: renders on this context now use the specialised kernel */
+    uint32_t from_cache; /* 1: the code object came from a cache, 0: it was compiled by this call */
+    double compile_ms;   /* time spent in hiprtc by this call */
+    uint32_t grid, vgprs;/* persistent grid of the kernel; 0 if unknown */
+} rt1w_specialise_info;
+int rt1w_context_specialise(rt1w_context* c, uint32_t flags, rt1w_specialise_info* info /* may be NULL */);
 
 /* ---- output side (src/color.rs) ---- */
 

@@ -38,7 +38,9 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#if !defined(__HIPCC_RTC__) /* the run-time compiler has the runtime header built in */
 #include <hip/hip_runtime.h>
+#endif
 #define RT_HD __host__ __device__ __forceinline__
 #else
 #define RT_HD inline

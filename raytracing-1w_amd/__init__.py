@@ -35,6 +35,8 @@ ROWS_F64, ROWS_U8 = 0, 1
 OUT_SUM = 1
 UNSORTED = 2
 LDS_NODES = 4
+GENERIC = 8  # do not use a scene-specialised kernel for this render
+SPECIALISE_CACHED_ONLY = 1
 
 
 class Rt1wError(RuntimeError):
@@ -47,6 +49,11 @@ class RenderParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
         "max_depth", "global_seed", "chunk", "flags")]
+
+
+class SpecialiseInfo(C.Structure):
+    _fields_ = [("key", C.c_char * 24), ("active", C.c_uint32), ("from_cache", C.c_uint32), ("compile_ms", C.c_double),
+                ("grid", C.c_uint32), ("vgprs", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -111,6 +118,7 @@ _sig("rt1w_scene_copy_flat", C.c_int64, _P, C.c_int, _P, C.c_uint64)
 _sig("rt1w_device_count", C.c_int)
 _sig("rt1w_context_create", C.c_int, C.c_int, _P, C.POINTER(_P))
 _sig("rt1w_context_destroy", None, _P)
+_sig("rt1w_context_specialise", C.c_int, _P, C.c_uint32, C.POINTER(SpecialiseInfo))
 _sig("rt1w_default_chunk", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("rt1w_render", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
@@ -301,15 +309,30 @@ class Context:
     __del__ = close
 
     @staticmethod
-    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False):
+    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        flags = (OUT_SUM if out_sum else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        flags = (OUT_SUM if out_sum else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (((variant + 1) << 8) if variant is not None else 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags)
 
+    def specialise(self, cached_only=False):
+        """Load (from the kernel cache) or compile (hiprtc, 3-5 s) the kernel specialised for this scene's topology
+        (rt1w_context_specialise).  Returns the info dict; raises Rt1wError for scenes of more than 64 nodes
+        (ERR_UNSUPPORTED) or, with cached_only, on a cache miss (ERR_STATE)."""
+        info = SpecialiseInfo()
+        _ck(_lib.rt1w_context_specialise(self._h, SPECIALISE_CACHED_ONLY if cached_only else 0, C.byref(info)))
+        return {"key": info.key.decode(), "active": bool(info.active), "from_cache": bool(info.from_cache),
+                "compile_ms": info.compile_ms, "grid": info.grid, "vgprs": info.vgprs}
+
+    def specialised(self):
+        """True if renders on this context use a scene-specialised kernel (cache hit at creation or specialise())."""
+        info = SpecialiseInfo()
+        rc = _lib.rt1w_context_specialise(self._h, SPECIALISE_CACHED_ONLY, C.byref(info))
+        return rc == 0 and bool(info.active)
+
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-               variant=None, unsorted=False, lds_nodes=False):
+               variant=None, unsorted=False, lds_nodes=False, generic=False):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict)."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic)
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
         st = Stats()
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))

@@ -21,6 +21,7 @@
 
 #include <chrono>
 #include <type_traits>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -46,19 +47,12 @@ __device__ __forceinline__ void rt_stamp_fn(int k) {
 }
 #define RT_STAMP(k) rt_stamp_fn(k)
 #endif
-#include "rt_core.h"
+#include "rt_kernel_sorted.h"
 #include "scene.h"
-
-#define RT_BLOCK 256
+#include "jit.h"
 
 namespace {
 
-struct LdsStack {
-    uint32_t* base; /* this lane's entry 0; entry e at base[e * RT_BLOCK] */
-    int sp;
-    __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
-    __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
-};
 /* 16-bit entries (node index < 32768, wrapper-exit flag in bit 15): half the LDS, used together with
  * the LDS node cache */
 struct LdsStack16 {
@@ -74,10 +68,6 @@ struct LdsNodes {
     const RtNodeHot* base;
     __device__ __forceinline__ RtNodeHot hot(uint32_t n) const { return base[n]; }
 };
-
-__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 /* counters[0] = next work item, counters[1] = traced segments */
 #ifndef RT_SWEEP_WAVES
@@ -172,182 +162,11 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVE
 #endif
 }
 
-/* ---- render kernel with workgroup-level reordering ------------------------------------------
- * Same per-path arithmetic as rt_render_kernel; what changes is WHICH LANE runs which path.
- * Every iteration, between the closest-hit search and the shading, the 256 paths of a workgroup
- * are sorted by what they have to do next (Lambertian / dielectric / metal / other scatter /
- * terminal / idle): per-wave ballots + mbcnt give each lane its rank, a 4x6 count table in LDS
- * gives the class bases, and every lane hands its whole path state (52 dwords) to the lane at its
- * sorted position through an LDS exchange buffer ([qword][slot], so the gather side is
- * conflict-free).  Waves then shade (mostly) one material each instead of every wave running
- * every material's code for a few lanes, and the paths that ended sit together in the last
- * wave(s), so regeneration is coherent too.  Results cannot depend on the lane a path runs on
- * (a path is a pure function of its state; a pixel chunk's samples still run one after the other
- * and are summed in order), so the framebuffer is bit-identical to the unsorted kernel's. */
-#define RT_XCH_QW 26 /* qwords of per-path state exchanged */
-#ifndef RT_SORT_BLOCK
-#define RT_SORT_BLOCK 256 /* paths sorted together = workgroup size of the reordering kernel */
-#endif
+/* the reordering kernel proper (rt_kernel_sorted.h) */
 template <class Cfg>
-__global__ __launch_bounds__(RT_SORT_BLOCK, Cfg::sweep && !Cfg::media ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
-                                                                      unsigned long long* __restrict__ counters) {
-    constexpr int NW = RT_SORT_BLOCK / 64;
-    static_assert(Cfg::sweep, "the reordering kernel is built for the stackless variants");
-    __shared__ unsigned long long xch[RT_XCH_QW * RT_SORT_BLOCK];
-    __shared__ uint32_t cnt[NW][RT_N_CLS];
-    LdsStack stk;
-    stk.base = nullptr;
-    stk.sp = 0;
-    RtGlobalNodes ns{sc.nodes};
-
-    const unsigned long long n_items = rt_item_count(f);
-    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long item = (unsigned long long)blockIdx.x * RT_SORT_BLOCK + threadIdx.x;
-    bool fresh = true, have = false, retired = false;
-    uint32_t px = 0, py = 0, chunk = 0, s = 0;
-    RtV3 sum = rt_v3(0.0, 0.0, 0.0);
-    RtPath path;
-    path.alive = false;
-    path.depth_left = 0u;
-    path.ray.o = path.ray.d = path.beta = path.radiance = rt_v3(0.0, 0.0, 0.0);
-    path.ray.time = 0.0;
-    path.rng = rt_rng_make(0u, 0u, 0u, f.global_seed, RT_DOMAIN_RENDER);
-    unsigned long long segs = 0;
-#ifdef RT_STAMPS
-    if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 16; ++k) rt_stamp_acc[threadIdx.x >> 6][k] = 0;
-        rt_stamp_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-
-    for (;;) {
-        RT_STAMP(6);
-        /* 1. regeneration: next sample of the lane's item, or a new item */
-        if (!path.alive && !retired) {
-            uint32_t s_end = chunk * f.chunk + f.chunk < f.spp ? chunk * f.chunk + f.chunk : f.spp;
-            if (have && s == s_end) {
-                double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
-                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
-                have = false;
-            }
-            while (!have) {
-                if (!fresh) {
-                    unsigned long long need = __ballot(1);
-                    uint32_t cntn = (uint32_t)__popcll(need);
-                    uint32_t rank = lane_prefix(need);
-                    unsigned long long base_item = 0;
-                    if (rank == 0u) base_item = atomicAdd(&counters[0], (unsigned long long)cntn);
-                    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_item);
-                    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_item >> 32));
-                    item = (((unsigned long long)hi << 32) | lo) + rank;
-                }
-                fresh = false;
-                if (item >= n_items) break;
-                rt_item_decode(f, item, px, py, chunk);
-                if (px < f.tile_w && py < f.tile_h) {
-                    s = chunk * f.chunk;
-                    sum = rt_v3(0.0, 0.0, 0.0);
-                    have = true;
-                }
-            }
-            if (!have) retired = true;
-            else rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
-        }
-        RT_STAMP(1);
-        /* 2. closest hit + class */
-        RtTrace tr;
-        tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_IDLE;
-        if (!retired) {
-            segs += path.depth_left != 0u ? 1ull : 0ull;
-            tr = rt_path_trace<Cfg>(sc, ns, path, stk);
-        }
-        RT_STAMP(2);
-        /* 3. sort the workgroup's paths by class */
-        uint32_t my_rank = 0;
-#pragma unroll
-        for (uint32_t c = 0; c < RT_N_CLS; ++c) {
-            unsigned long long m = __ballot(tr.cls == c);
-            if (tr.cls == c) my_rank = lane_prefix(m);
-            if (lane == 0u) cnt[wave][c] = (uint32_t)__popcll(m);
-        }
-        __syncthreads();
-        uint32_t dest = my_rank, idle_total = 0;
-#pragma unroll
-        for (uint32_t c = 0; c < RT_N_CLS; ++c) {
-#pragma unroll
-            for (uint32_t w = 0; w < (uint32_t)NW; ++w) {
-                uint32_t v = cnt[w][c];
-                if (c < tr.cls || (c == tr.cls && w < wave)) dest += v;
-                if (c == RT_CLS_IDLE) idle_total += v;
-            }
-        }
-        if (idle_total == RT_SORT_BLOCK) break; /* every path of the workgroup is done (uniform) */
-        {
-            unsigned long long* q = xch + dest;
-#define RT_PUT64(x) do { *q = (x); q += RT_SORT_BLOCK; } while (0)
-#define RT_PUTD(x) RT_PUT64(rt_d2u(x))
-#define RT_PUT2(a, b) RT_PUT64(((unsigned long long)(b) << 32) | (unsigned long long)(uint32_t)(a))
-            RT_PUTD(path.ray.o.x); RT_PUTD(path.ray.o.y); RT_PUTD(path.ray.o.z);
-            RT_PUTD(path.ray.d.x); RT_PUTD(path.ray.d.y); RT_PUTD(path.ray.d.z);
-            RT_PUTD(path.ray.time);
-            RT_PUTD(path.beta.x); RT_PUTD(path.beta.y); RT_PUTD(path.beta.z);
-            RT_PUTD(sum.x); RT_PUTD(sum.y); RT_PUTD(sum.z);
-            RT_PUTD(tr.t);
-            RT_PUT2(path.rng.k0, path.rng.k1); RT_PUT2(path.rng.c1, path.rng.blk);
-            RT_PUT2(path.rng.left, path.rng.bv); RT_PUT2(path.rng.a0, path.rng.a1);
-            RT_PUT2(path.rng.a2, path.rng.a3); RT_PUT2(path.rng.b0, path.rng.b1);
-            RT_PUT2(path.rng.b2, path.rng.b3);
-            RT_PUT2(tr.prim, tr.scope); RT_PUT2(tr.cls, path.depth_left);
-            RT_PUT2(px, py); RT_PUT2(chunk, s);
-            RT_PUT2((have ? 1u : 0u) | (retired ? 2u : 0u) | (path.alive ? 4u : 0u), 0u);
-#undef RT_PUT64
-#undef RT_PUTD
-#undef RT_PUT2
-        }
-        __syncthreads();
-        {
-            const unsigned long long* q = xch + threadIdx.x;
-            unsigned long long v_;
-#define RT_GET64() (v_ = *q, q += RT_SORT_BLOCK, v_)
-#define RT_GETD(x) (x) = rt_u2d(RT_GET64())
-#define RT_GET2(a, b) do { unsigned long long t_ = RT_GET64(); (a) = (uint32_t)t_; (b) = (uint32_t)(t_ >> 32); } while (0)
-            RT_GETD(path.ray.o.x); RT_GETD(path.ray.o.y); RT_GETD(path.ray.o.z);
-            RT_GETD(path.ray.d.x); RT_GETD(path.ray.d.y); RT_GETD(path.ray.d.z);
-            RT_GETD(path.ray.time);
-            RT_GETD(path.beta.x); RT_GETD(path.beta.y); RT_GETD(path.beta.z);
-            RT_GETD(sum.x); RT_GETD(sum.y); RT_GETD(sum.z);
-            RT_GETD(tr.t);
-            RT_GET2(path.rng.k0, path.rng.k1); RT_GET2(path.rng.c1, path.rng.blk);
-            RT_GET2(path.rng.left, path.rng.bv); RT_GET2(path.rng.a0, path.rng.a1);
-            RT_GET2(path.rng.a2, path.rng.a3); RT_GET2(path.rng.b0, path.rng.b1);
-            RT_GET2(path.rng.b2, path.rng.b3);
-            RT_GET2(tr.prim, tr.scope); RT_GET2(tr.cls, path.depth_left);
-            RT_GET2(px, py); RT_GET2(chunk, s);
-            uint32_t flags, zero_;
-            RT_GET2(flags, zero_);
-            have = (flags & 1u) != 0u; retired = (flags & 2u) != 0u; path.alive = (flags & 4u) != 0u;
-#undef RT_GET64
-#undef RT_GETD
-#undef RT_GET2
-        }
-        RT_STAMP(7);
-        /* 4. shading (coherent within a wave after the sort) */
-        if (!retired) {
-            rt_path_shade<Cfg>(sc, path, tr);
-            if (!path.alive) {
-                sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
-                path.radiance = rt_v3(0.0, 0.0, 0.0);
-                ++s;
-            }
-        }
-        RT_STAMP(5);
-    }
-    if (segs) atomicAdd(&counters[1], segs);
-#ifdef RT_STAMPS
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 16; ++k) atomicAdd(&g_stamp_total[k], rt_stamp_acc[threadIdx.x >> 6][k]);
-#endif
+__global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+                                                                                       unsigned long long* __restrict__ counters) {
+    rt_render_sorted_body<Cfg>(sc, f, partial, counters);
 }
 
 /* Sum the chunk partials of each pixel in chunk order; then Color::into_sampled
@@ -442,6 +261,13 @@ struct rt1w_context {
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
+    /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
+    std::string jit_src, jit_key;
+    hipModule_t jit_mod = nullptr;
+    hipFunction_t jit_fn = nullptr;
+    int jit_grid = 0;
+    uint32_t jit_vgprs = 0;
+    bool jit_failed = false; /* a compile was tried and failed: do not try again on this context */
 };
 
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
@@ -498,7 +324,7 @@ void lane_destroy(RtLane& l) {
     l = RtLane();
 }
 
-struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached; };
+struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit; };
 
 /* what the launch will need, without launching: frame, variant, launch shape */
 int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
@@ -519,6 +345,8 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
         }
     }
     L.variant = variant;
+    L.jit = c->jit_fn != nullptr && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED | RT1W_LDS_NODES)) && !(p->flags >> 8);
+    if (L.jit) { L.sorted = true; L.cached = false; L.grid = c->jit_grid; L.block = RT_SORT_BLOCK; return RT1W_OK; }
     L.sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
     L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : c->grid[variant]);
@@ -541,8 +369,17 @@ int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
 int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const RtLaunch& L, double* d_out) {
     hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block);
     (void)hipEventRecord(l.ev0, l.stream);
-    hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : g_kernels[L.variant]),
-                       dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
+    if (L.jit) {
+        RtSceneView view = c->view;
+        RtFrame frame = L.f;
+        double* partial = l.d_partial;
+        unsigned long long* counters = l.d_counters;
+        void* args[] = {&view, &frame, &partial, &counters};
+        if (!hip_ok(hipModuleLaunchKernel(c->jit_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised kernel launch")) return RT1W_ERR_DEVICE;
+    } else {
+        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : g_kernels[L.variant]),
+                           dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
+    }
     {
         unsigned int rb = 256;
         unsigned int rg = (unsigned int)((L.npix + rb - 1) / rb);
@@ -566,12 +403,43 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u);
     }
     return RT1W_OK;
 }
 
+/* load the specialised kernel of this context's scene: from the caches, or (allow_compile) from the compiler */
+int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
+    if (c->jit_fn) { info = rt1w::JitInfo(); info.key = c->jit_key; info.from_cache = true; return RT1W_OK; }
+    if (c->jit_src.empty()) { rt1w::set_error("scene has more than RT_SWEEP_MAX_NODES nodes: no specialised kernel"); return RT1W_ERR_UNSUPPORTED; }
+    std::vector<char> code;
+    int rc = rt1w::jit_get_code(c->jit_src, allow_compile, code, info);
+    c->jit_key = info.key;
+    if (rc < 0) { rt1w::set_error("specialised kernel: " + info.message); return rc; }
+    if (!hip_ok(hipModuleLoadData(&c->jit_mod, code.data()), "hipModuleLoadData(specialised kernel)")) { c->jit_mod = nullptr; return RT1W_ERR_DEVICE; }
+    hipFunction_t fn = nullptr;
+    if (!hip_ok(hipModuleGetFunction(&fn, c->jit_mod, "rt_jit_sorted"), "hipModuleGetFunction")) {
+        (void)hipModuleUnload(c->jit_mod); c->jit_mod = nullptr; return RT1W_ERR_DEVICE;
+    }
+    int per_cu = 0;
+    if (!hip_ok(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_SORT_BLOCK, 0), "occupancy query")) per_cu = 1;
+    if (per_cu < 1) per_cu = 1;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) { (void)hipModuleUnload(c->jit_mod); c->jit_mod = nullptr; return RT1W_ERR_DEVICE; }
+    int vg = 0;
+    if (hipFuncGetAttribute(&vg, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn) == hipSuccess) c->jit_vgprs = (uint32_t)vg;
+    c->jit_grid = prop.multiProcessorCount * per_cu;
+    c->jit_fn = fn;
+    return RT1W_OK;
+}
+
 int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, rt1w_stats* stats) {
+    /* a render this long repays the 3-5 s of the compiler (RT1W_NO_JIT: never compile behind the caller's back) */
+    if (!c->jit_fn && !c->jit_failed && !c->jit_src.empty() && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) &&
+        (unsigned long long)p->tile_w * p->tile_h * p->spp >= (1ull << 35) && !getenv("RT1W_NO_JIT")) {
+        rt1w::JitInfo info;
+        if (specialise(c, true, info) < 0) c->jit_failed = true;
+    }
     RtLaunch L;
     int rc = render_plan(c, p, L);
     if (rc < 0) return rc;
@@ -669,6 +537,11 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->n_nodes = (uint32_t)s->flat_nodes.size();
     c->scope_depth = s->scope_depth;
     c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth);
+    if (rt1w::jit_eligible(*s)) {
+        c->jit_src = rt1w::jit_source(*s);
+        rt1w::JitInfo info;
+        (void)specialise(c, false, info); /* a cache hit is used from the first render on; a miss costs nothing */
+    }
     *out = c;
     return RT1W_OK;
 }
@@ -680,8 +553,26 @@ void rt1w_context_destroy(rt1w_context* c) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     lane_destroy(c->lane[0]);
     lane_destroy(c->lane[1]);
+    if (c->jit_mod) (void)hipModuleUnload(c->jit_mod);
     if (c->ev_first) (void)hipEventDestroy(c->ev_first);
     delete c;
+}
+
+int rt1w_context_specialise(rt1w_context* c, uint32_t flags, rt1w_specialise_info* out) {
+    if (!c) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    rt1w::JitInfo info;
+    const bool had = c->jit_fn != nullptr;
+    int rc = specialise(c, !(flags & RT1W_SPECIALISE_CACHED_ONLY), info);
+    if (out) {
+        memset(out, 0, sizeof *out);
+        snprintf(out->key, sizeof out->key, "%s", c->jit_key.c_str());
+        out->active = c->jit_fn ? 1u : 0u;
+        out->from_cache = (had || info.from_cache) ? 1u : 0u;
+        out->compile_ms = info.compile_ms;
+        out->grid = (uint32_t)c->jit_grid; out->vgprs = c->jit_vgprs;
+    }
+    return rc;
 }
 
 int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out_rgb, rt1w_stats* stats) {

@@ -24,6 +24,7 @@
 #ifndef RT1W_CORE_H
 #define RT1W_CORE_H
 
+#include <type_traits>
 #include "rt_flat.h"
 
 #define RT_POP_FLAG 0x80000000u
@@ -558,10 +559,96 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
     return best_prim != RT_NONE;
 }
 
+/* The same sweep for a scene whose node kinds and subtree ends are known at compile time (Topo::kind[], Topo::skip[]):
+ * the loop over n is unrolled into straight-line code that follows the tree -- a subtree's code is guarded by "some
+ * lane of the wave is at its root", node kinds need no dispatch, the node record of step I is fetched at a constant
+ * offset, and a wrapper's subtree simply runs with the inner ray while the outer one stays live.  Every lane still
+ * visits exactly the nodes of the reference's walk, in its order, with the same arithmetic. */
+template <class Topo, class Cfg, bool MEDIA, uint32_t I, uint32_t END, class NS>
+RT_HD void rt_sweep_static(const RtSceneView& sc, const NS& ns, const RtRayOD& ray, const RtV3& inv, double time, double t_min,
+                           bool tmin_nan, RtRng& rng, uint32_t& cur, double& best_t, uint32_t& best_prim) {
+    if constexpr (I < END) {
+        constexpr uint32_t kind = Topo::kind[I] & RT_KIND_MASK;
+        constexpr uint32_t skip = Topo::skip[I];
+        if constexpr (kind <= RT_BVH1) {
+            if (RT_WAVE_ANY(cur == I)) {
+                const RtNodeHot nd = ns.hot(I);
+                if (cur == I) {
+                    bool hit;
+                    if (RT_WAVE_ANY(tmin_nan || rt_isnan(best_t))) hit = rt_aabb_hit(nd.d, ray.o, inv, t_min, best_t);
+                    else hit = rt_aabb_hit_fast(nd.d, ray.o, inv, t_min, best_t);
+                    cur = hit ? I + 1u : skip;
+                }
+                rt_sweep_static<Topo, Cfg, MEDIA, I + 1u, skip>(sc, ns, ray, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+            }
+            rt_sweep_static<Topo, Cfg, MEDIA, skip, END>(sc, ns, ray, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+        } else if constexpr (kind <= RT_YZ) {
+            if (RT_WAVE_ANY(cur == I)) {
+                const RtNodeHot nd = ns.hot(I);
+                if (cur == I) {
+                    double t;
+                    bool hit;
+                    if constexpr (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(sc.nodes[I], kind, ray.o, ray.d, time, t_min, best_t, t);
+                    else hit = rt_prim_hot_t(nd, kind, ray.o, ray.d, t_min, best_t, t);
+                    if (hit) { best_t = t; best_prim = I; }
+                    cur = I + 1u;
+                }
+            }
+            rt_sweep_static<Topo, Cfg, MEDIA, I + 1u, END>(sc, ns, ray, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+        } else if constexpr (kind <= RT_FLIP) {
+            if (RT_WAVE_ANY(cur == I)) {
+                const RtNodeHot nd = ns.hot(I);
+                cur = (cur == I) ? I + 1u : cur;
+                if constexpr (kind == RT_FLIP) {
+                    rt_sweep_static<Topo, Cfg, MEDIA, I + 1u, skip>(sc, ns, ray, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+                } else {
+                    /* Translate::hit hittable.rs:207-211 / RotateY::hit :238-251 */
+                    const RtRayOD inner = rt_scope_in(nd, ray);
+                    if constexpr (kind == RT_ROTATE_Y) {
+                        const RtV3 inv_inner = rt_inv3(inner.d);
+                        rt_sweep_static<Topo, Cfg, MEDIA, I + 1u, skip>(sc, ns, inner, inv_inner, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+                    } else {
+                        rt_sweep_static<Topo, Cfg, MEDIA, I + 1u, skip>(sc, ns, inner, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+                    }
+                }
+            }
+            rt_sweep_static<Topo, Cfg, MEDIA, skip, END>(sc, ns, ray, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+        } else {
+            if (RT_WAVE_ANY(cur == I)) {
+                if (cur == I) {
+                    if constexpr (MEDIA && Cfg::media && kind == RT_MEDIUM) {
+                        /* ConstantMedium::hit constant_medium.rs:58-113: the boundary is a sweep of its own subtree */
+                        const RtNode& full = sc.nodes[I];
+                        double t1 = RT_INF, t2 = RT_INF, t;
+                        uint32_t c1 = I + 1u, p1 = RT_NONE, c2 = I + 1u, p2 = RT_NONE;
+                        rt_sweep_static<Topo, Cfg, false, I + 1u, skip>(sc, ns, ray, inv, time, -RT_INF, false, rng, c1, t1, p1);
+                        if (p1 != RT_NONE) {
+                            const double lo = t1 + 0.0001;
+                            rt_sweep_static<Topo, Cfg, false, I + 1u, skip>(sc, ns, ray, inv, time, lo, rt_isnan(lo), rng, c2, t2, p2);
+                            if (p2 != RT_NONE && rt_medium_t(full, ray.d, t1, t2, t_min, best_t, rng, t)) { best_t = t; best_prim = I; }
+                        }
+                    }
+                    cur = skip;
+                }
+            }
+            rt_sweep_static<Topo, Cfg, MEDIA, skip, END>(sc, ns, ray, inv, time, t_min, tmin_nan, rng, cur, best_t, best_prim);
+        }
+    }
+}
+
 template <class Cfg, class Stack, class NS>
 RT_HD bool rt_closest_hit(const RtSceneView& sc, const NS& ns, const RtRay& ray, double t_min, double t_max, RtRng& rng,
                           Stack& stk, double& t, uint32_t& prim, uint32_t& scope) {
-    if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, t, prim, scope);
+    if constexpr (Cfg::sweep && !std::is_void<typename Cfg::Topo>::value) {
+        typedef typename Cfg::Topo Topo;
+        RtRayOD w; w.o = ray.o; w.d = ray.d;
+        const RtV3 inv = rt_inv3(w.d);
+        uint32_t cur = Topo::root;
+        t = t_max; prim = RT_NONE;
+        rt_sweep_static<Topo, Cfg, true, Topo::root, Topo::skip[Topo::root]>(sc, ns, w, inv, ray.time, t_min, rt_isnan(t_min), rng, cur, t, prim);
+        scope = prim == RT_NONE ? RT_NONE : ns.hot(prim).b; /* leaves keep their innermost wrapper in `b` */
+        return prim != RT_NONE;
+    } else if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, t, prim, scope);
     else return rt_traverse_stack<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
 }
 

@@ -45,7 +45,7 @@ struct RtNode {
     uint32_t kind;
     uint32_t skip; /* nodes are stored in depth-first pre-order: [index, skip) is this node's subtree */
     double d[6];
-    uint32_t b;    /* BVH2: right child; wrapper: parent wrapper (RT_NONE at top level) */
+    uint32_t b;    /* BVH2: right child; wrapper / leaf / medium: the wrapper above it (RT_NONE at top level) */
     uint32_t mat;
     double e[3];   /* MovingSphere only: time0, time1, radius */
     uint32_t a;    /* == index + 1 for BVH / wrapper / medium nodes */
@@ -139,8 +139,10 @@ struct RtFrame {
 
 /* compile-time feature set of a kernel variant: code for absent features is not
  * generated, which is what keeps the register budget of the simple scenes low */
-template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_, int SCOPE_DEPTH_ = 3>
+/* `Topo_`: void, or a type with the scene's node kinds and subtree ends as compile-time arrays (rt_sweep_static) */
+template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_, int SCOPE_DEPTH_ = 3, class Topo_ = void>
 struct RtCfg {
+    typedef Topo_ Topo;
     static constexpr int scope_depth = SCOPE_DEPTH_; /* deepest wrapper nesting the sweep variant handles */
     static constexpr bool media = MEDIA_;     /* scene contains ConstantMedium nodes */
     static constexpr bool tex = TEX_;         /* scene has non-solid textures (checker/noise/image) */

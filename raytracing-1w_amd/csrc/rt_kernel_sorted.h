@@ -1,0 +1,200 @@
+/* rt_kernel_sorted.h -- body of the reordering render kernel, shared by the kernels built into librt1w.so
+ * (context.hip) and by the topology-specialised kernels compiled at run time with hiprtc (jit.cpp). */
+#ifndef RT_KERNEL_SORTED_H
+#define RT_KERNEL_SORTED_H
+
+#include "rt_core.h"
+
+#define RT_BLOCK 256
+
+struct LdsStack {
+    uint32_t* base; /* this lane's entry 0; entry e at base[e * RT_BLOCK] */
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
+    __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
+};
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+/* ---- render kernel with workgroup-level reordering ------------------------------------------
+ * Same per-path arithmetic as rt_render_kernel; what changes is WHICH LANE runs which path.
+ * Every iteration, between the closest-hit search and the shading, the 256 paths of a workgroup
+ * are sorted by what they have to do next (Lambertian / dielectric / metal / other scatter /
+ * terminal / idle): per-wave ballots + mbcnt give each lane its rank, a 4x6 count table in LDS
+ * gives the class bases, and every lane hands its whole path state (52 dwords) to the lane at its
+ * sorted position through an LDS exchange buffer ([qword][slot], so the gather side is
+ * conflict-free).  Waves then shade (mostly) one material each instead of every wave running
+ * every material's code for a few lanes, and the paths that ended sit together in the last
+ * wave(s), so regeneration is coherent too.  Results cannot depend on the lane a path runs on
+ * (a path is a pure function of its state; a pixel chunk's samples still run one after the other
+ * and are summed in order), so the framebuffer is bit-identical to the unsorted kernel's. */
+#define RT_XCH_QW 26 /* qwords of per-path state exchanged */
+#ifndef RT_SORT_BLOCK
+#define RT_SORT_BLOCK 256 /* paths sorted together = workgroup size of the reordering kernel */
+#endif
+#define RT_SORT_WAVES(Cfg) ((Cfg::sweep && !Cfg::media) ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2) /* waves per SIMD the kernel is built for */
+template <class Cfg>
+__device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, const RtFrame& f, double* __restrict__ partial,
+                                                      unsigned long long* __restrict__ counters) {
+    constexpr int NW = RT_SORT_BLOCK / 64;
+    static_assert(Cfg::sweep, "the reordering kernel is built for the stackless variants");
+    __shared__ unsigned long long xch[RT_XCH_QW * RT_SORT_BLOCK];
+    __shared__ uint32_t cnt[NW][RT_N_CLS];
+    LdsStack stk;
+    stk.base = nullptr;
+    stk.sp = 0;
+    RtGlobalNodes ns{sc.nodes};
+
+    const unsigned long long n_items = rt_item_count(f);
+    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long item = (unsigned long long)blockIdx.x * RT_SORT_BLOCK + threadIdx.x;
+    bool fresh = true, have = false, retired = false;
+    uint32_t px = 0, py = 0, chunk = 0, s = 0;
+    RtV3 sum = rt_v3(0.0, 0.0, 0.0);
+    RtPath path;
+    path.alive = false;
+    path.depth_left = 0u;
+    path.ray.o = path.ray.d = path.beta = path.radiance = rt_v3(0.0, 0.0, 0.0);
+    path.ray.time = 0.0;
+    path.rng = rt_rng_make(0u, 0u, 0u, f.global_seed, RT_DOMAIN_RENDER);
+    unsigned long long segs = 0;
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 16; ++k) rt_stamp_acc[threadIdx.x >> 6][k] = 0;
+        rt_stamp_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+
+    for (;;) {
+        RT_STAMP(6);
+        /* 1. regeneration: next sample of the lane's item, or a new item */
+        if (!path.alive && !retired) {
+            uint32_t s_end = chunk * f.chunk + f.chunk < f.spp ? chunk * f.chunk + f.chunk : f.spp;
+            if (have && s == s_end) {
+                double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
+                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
+                have = false;
+            }
+            while (!have) {
+                if (!fresh) {
+                    unsigned long long need = __ballot(1);
+                    uint32_t cntn = (uint32_t)__popcll(need);
+                    uint32_t rank = lane_prefix(need);
+                    unsigned long long base_item = 0;
+                    if (rank == 0u) base_item = atomicAdd(&counters[0], (unsigned long long)cntn);
+                    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_item);
+                    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_item >> 32));
+                    item = (((unsigned long long)hi << 32) | lo) + rank;
+                }
+                fresh = false;
+                if (item >= n_items) break;
+                rt_item_decode(f, item, px, py, chunk);
+                if (px < f.tile_w && py < f.tile_h) {
+                    s = chunk * f.chunk;
+                    sum = rt_v3(0.0, 0.0, 0.0);
+                    have = true;
+                }
+            }
+            if (!have) retired = true;
+            else rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+        }
+        RT_STAMP(1);
+        /* 2. closest hit + class */
+        RtTrace tr;
+        tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_IDLE;
+        if (!retired) {
+            segs += path.depth_left != 0u ? 1ull : 0ull;
+            tr = rt_path_trace<Cfg>(sc, ns, path, stk);
+        }
+        RT_STAMP(2);
+        /* 3. sort the workgroup's paths by class */
+        uint32_t my_rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < RT_N_CLS; ++c) {
+            unsigned long long m = __ballot(tr.cls == c);
+            if (tr.cls == c) my_rank = lane_prefix(m);
+            if (lane == 0u) cnt[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        uint32_t dest = my_rank, idle_total = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < RT_N_CLS; ++c) {
+#pragma unroll
+            for (uint32_t w = 0; w < (uint32_t)NW; ++w) {
+                uint32_t v = cnt[w][c];
+                if (c < tr.cls || (c == tr.cls && w < wave)) dest += v;
+                if (c == RT_CLS_IDLE) idle_total += v;
+            }
+        }
+        if (idle_total == RT_SORT_BLOCK) break; /* every path of the workgroup is done (uniform) */
+        {
+            unsigned long long* q = xch + dest;
+#define RT_PUT64(x) do { *q = (x); q += RT_SORT_BLOCK; } while (0)
+#define RT_PUTD(x) RT_PUT64(rt_d2u(x))
+#define RT_PUT2(a, b) RT_PUT64(((unsigned long long)(b) << 32) | (unsigned long long)(uint32_t)(a))
+            RT_PUTD(path.ray.o.x); RT_PUTD(path.ray.o.y); RT_PUTD(path.ray.o.z);
+            RT_PUTD(path.ray.d.x); RT_PUTD(path.ray.d.y); RT_PUTD(path.ray.d.z);
+            RT_PUTD(path.ray.time);
+            RT_PUTD(path.beta.x); RT_PUTD(path.beta.y); RT_PUTD(path.beta.z);
+            RT_PUTD(sum.x); RT_PUTD(sum.y); RT_PUTD(sum.z);
+            RT_PUTD(tr.t);
+            RT_PUT2(path.rng.k0, path.rng.k1); RT_PUT2(path.rng.c1, path.rng.blk);
+            RT_PUT2(path.rng.left, path.rng.bv); RT_PUT2(path.rng.a0, path.rng.a1);
+            RT_PUT2(path.rng.a2, path.rng.a3); RT_PUT2(path.rng.b0, path.rng.b1);
+            RT_PUT2(path.rng.b2, path.rng.b3);
+            RT_PUT2(tr.prim, tr.scope); RT_PUT2(tr.cls, path.depth_left);
+            RT_PUT2(px, py); RT_PUT2(chunk, s);
+            RT_PUT2((have ? 1u : 0u) | (retired ? 2u : 0u) | (path.alive ? 4u : 0u), 0u);
+#undef RT_PUT64
+#undef RT_PUTD
+#undef RT_PUT2
+        }
+        __syncthreads();
+        {
+            const unsigned long long* q = xch + threadIdx.x;
+            unsigned long long v_;
+#define RT_GET64() (v_ = *q, q += RT_SORT_BLOCK, v_)
+#define RT_GETD(x) (x) = rt_u2d(RT_GET64())
+#define RT_GET2(a, b) do { unsigned long long t_ = RT_GET64(); (a) = (uint32_t)t_; (b) = (uint32_t)(t_ >> 32); } while (0)
+            RT_GETD(path.ray.o.x); RT_GETD(path.ray.o.y); RT_GETD(path.ray.o.z);
+            RT_GETD(path.ray.d.x); RT_GETD(path.ray.d.y); RT_GETD(path.ray.d.z);
+            RT_GETD(path.ray.time);
+            RT_GETD(path.beta.x); RT_GETD(path.beta.y); RT_GETD(path.beta.z);
+            RT_GETD(sum.x); RT_GETD(sum.y); RT_GETD(sum.z);
+            RT_GETD(tr.t);
+            RT_GET2(path.rng.k0, path.rng.k1); RT_GET2(path.rng.c1, path.rng.blk);
+            RT_GET2(path.rng.left, path.rng.bv); RT_GET2(path.rng.a0, path.rng.a1);
+            RT_GET2(path.rng.a2, path.rng.a3); RT_GET2(path.rng.b0, path.rng.b1);
+            RT_GET2(path.rng.b2, path.rng.b3);
+            RT_GET2(tr.prim, tr.scope); RT_GET2(tr.cls, path.depth_left);
+            RT_GET2(px, py); RT_GET2(chunk, s);
+            uint32_t flags, zero_;
+            RT_GET2(flags, zero_);
+            have = (flags & 1u) != 0u; retired = (flags & 2u) != 0u; path.alive = (flags & 4u) != 0u;
+#undef RT_GET64
+#undef RT_GETD
+#undef RT_GET2
+        }
+        RT_STAMP(7);
+        /* 4. shading (coherent within a wave after the sort) */
+        if (!retired) {
+            rt_path_shade<Cfg>(sc, path, tr);
+            if (!path.alive) {
+                sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
+                path.radiance = rt_v3(0.0, 0.0, 0.0);
+                ++s;
+            }
+        }
+        RT_STAMP(5);
+    }
+    if (segs) atomicAdd(&counters[1], segs);
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 16; ++k) atomicAdd(&g_stamp_total[k], rt_stamp_acc[threadIdx.x >> 6][k]);
+#endif
+}
+
+#endif

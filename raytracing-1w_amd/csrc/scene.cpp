@@ -154,6 +154,7 @@ struct Flattener {
                 std::memcpy(n.d, h.d, sizeof n.d);
                 n.e[0] = h.d[6]; n.e[1] = h.d[7]; n.e[2] = h.d[8];
                 n.mat = (uint32_t)h.mat;
+                n.b = parent_scope; /* innermost wrapper above the leaf */
                 out.push_back(n);
                 return (uint32_t)out.size() - 1;
             }
@@ -208,6 +209,7 @@ struct Flattener {
                 RtNode n = blank(RT_MEDIUM);
                 n.d[0] = h.d[0];
                 n.mat = (uint32_t)h.mat;
+                n.b = parent_scope;
                 out.push_back(n);
                 uint32_t nc = 0;
                 /* the boundary is traversed with the medium's own ray as its outer ray */

@@ -395,3 +395,64 @@ def test_strip_render_with_progress_is_bit_identical(rt, gpu_ctx_factory):
     assert np.array_equal(again, ref8)
     with pytest.raises(rt.Rt1wError):
         ctx.render_rows(64, 64, 8, u8=True, out_sum=True)
+
+
+def test_scene_specialised_kernels_are_bit_identical(rt, gpu_ctx_factory, tmp_path, monkeypatch):
+    """rt1w_context_specialise: the sweep unrolled along the scene's own tree (compile-time node kinds), from the
+    in-tree kernel cache for the reference arms at build_seed 1, from hiprtc otherwise.  Same arithmetic, so the frames
+    must equal the generic kernels' bit for bit -- Cornell, the media arm, the textured arms, random graphs."""
+    monkeypatch.setenv("RT1W_KERNEL_CACHE", str(tmp_path / "kcache"))
+    # (1) the reference arms built into <package>/kernels: active from context creation on
+    for arm, (W, H, spp) in {5: (96, 96, 16), 6: (64, 64, 12), 1: (64, 36, 8), 2: (64, 36, 8), 3: (64, 36, 8), 4: (64, 36, 16)}.items():
+        sc = rt.Scene.reference(arm, build_seed=1)
+        ctx = gpu_ctx_factory(sc)
+        assert ctx.specialised(), f"arm {arm}: no precompiled kernel found next to the library"
+        a, sa = ctx.render(W, H, spp)
+        b, sb = ctx.render(W, H, spp, generic=True)
+        assert (sa["sorted"] & 4) and not (sb["sorted"] & 4)
+        assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), arm
+        f, _ = orc.flat_render(sc, W, H, spp, chunk=sa["chunk"])
+        assert np.array_equal(a, f, equal_nan=True), arm
+    # (2) another build seed = another tree: cache miss, compile, then a hit from the user cache
+    sc = rt.Scene.reference(5, build_seed=7)
+    ctx = gpu_ctx_factory(sc)
+    assert not ctx.specialised()
+    with pytest.raises(rt.Rt1wError) as e:
+        ctx.specialise(cached_only=True)
+    assert e.value.code == rt.ERR_STATE
+    g, sg = ctx.render(200, 200, 20)
+    assert not (sg["sorted"] & 4)
+    info = ctx.specialise()
+    assert info["active"] and not info["from_cache"] and info["compile_ms"] > 0 and len(info["key"]) == 16
+    s, ss = ctx.render(200, 200, 20)
+    assert (ss["sorted"] & 4) and np.array_equal(g, s, equal_nan=True) and ss["segments"] == sg["segments"]
+    ctx2 = gpu_ctx_factory(sc)
+    assert ctx2.specialised() and ctx2.specialise()["from_cache"]
+    # tiles, sample offsets, raw sums, strips go through the same launch path
+    t1, _ = ctx.render(200, 200, 9, tile=(13, 7, 50, 31), sample_offset=5, out_sum=True)
+    t2, _ = ctx.render(200, 200, 9, tile=(13, 7, 50, 31), sample_offset=5, out_sum=True, generic=True)
+    assert np.array_equal(t1, t2, equal_nan=True)
+    r, sr = ctx.render_rows(200, 200, 20, strip_rows=64)
+    assert (sr["sorted"] & 4) and np.array_equal(r, s, equal_nan=True)
+    # (3) random small graphs: wrappers nested up to 3, media with wrapped boundaries, every texture and primitive kind
+    from dual import random_scene_pair
+    done = 0
+    for seed in range(2000, 2040):
+        prod, _ = random_scene_pair(seed)
+        info = prod.info()
+        if info["n_nodes"] > 64:
+            continue
+        c = gpu_ctx_factory(prod)
+        c.specialise()
+        a, sa = c.render(28, 20, 4)
+        b, sb = c.render(28, 20, 4, generic=True)
+        assert (sa["sorted"] & 4) and sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (seed, info)
+        done += 1
+        if done == 6:
+            break
+    assert done == 6
+    # (4) big scenes keep the generic kernels
+    big = gpu_ctx_factory(rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5))
+    with pytest.raises(rt.Rt1wError) as e:
+        big.specialise()
+    assert e.value.code == rt.ERR_UNSUPPORTED and not big.specialised()
