@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="ablation: the generic kernel instead of the scene-specialised one")
     ap.add_argument("--spp", type=int, default=SPP, help="debug only; the contract workload is 1000")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only (1-GPU box): every rank uses this device instead of LOCAL_RANK")
@@ -77,9 +78,17 @@ def main():
     torch.cuda.set_device(local_rank)
     scene = rt.Scene.reference(5, build_seed=1)
     ctx = rt.Context(scene, local_rank)
+    # kernel specialised for this scene's topology: from the kernel cache the build fills (raytracing-1w_amd/kernels), or compiled
+    # here with hiprtc (3-5 s, outside the timed region like the rest of the set-up); --generic keeps the generic kernel
+    spec = None
+    if not a.generic:
+        try:
+            spec = ctx.specialise()
+        except rt.Rt1wError as e:
+            spec = {"active": False, "error": str(e)}
     spp = a.spp
     out = torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
-    kw = dict(max_depth=DEPTH, sample_offset=rank * spp, out_sum=(world > 1))
+    kw = dict(max_depth=DEPTH, sample_offset=rank * spp, out_sum=(world > 1), generic=a.generic)
 
     def barrier():
         if dist is not None:
@@ -133,10 +142,11 @@ def main():
                        "paths_per_step": paths_per_step, "segments_per_path": round(segs / (W * H * spp), 4),
                        "chunk": st["chunk"], "n_chunks": st["n_chunks"], "grid": st["grid"], "block": st["block"],
                        "kernel_variant": st["variant"], "workgroup_path_sort": bool(st.get("sorted", 0) & 1),
+                       "scene_specialised_kernel": bool(st.get("sorted", 0) & 4), "specialise": spec,
                        "parallelism": f"sample-range x{world}, host gather, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "rt_render_kernel_sorted<V%d>" % st["variant"] if (st.get("sorted", 0) & 1) else "rt_render_kernel<V%d>" % st["variant"],
+                         "kernel": "rt_jit_sorted" if (st.get("sorted", 0) & 4) else ("rt_render_kernel_sorted<V%d>" % st["variant"] if (st.get("sorted", 0) & 1) else "rt_render_kernel<V%d>" % st["variant"]),
                          "kernel_ms": round(avg_ms, 3),
                          "algorithmic_bytes_per_launch": algo_bytes, "pmc": pmc,
                          "note": "compute-bound f64 kernel: ray state stays in VGPRs, so real HBM traffic is far "

@@ -18,6 +18,13 @@
 
 #include "rt_core.h"
 
+/* tests/test_static_sweep.py compiles this file a second time with a generated header that defines scene topologies
+ * as compile-time arrays (what the library's run-time compiler does for the GPU, jit.cpp) and adds them as variants
+ * 100, 101, ...: the unrolled sweep (rt_sweep_static) against the generic one, on the CPU. */
+#ifdef ORC_STATIC_TOPO_H
+#include ORC_STATIC_TOPO_H
+#endif
+
 namespace {
 struct HostStack {
     uint32_t e[RT_STACK_CAP + 8];
@@ -87,6 +94,9 @@ int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint
                         case 0: run_path<RtCfgV0>(sc, f, px, py, s, stk, sum, segs); break;
                         case 1: run_path<RtCfgV1>(sc, f, px, py, s, stk, sum, segs); break;
                         case 2: run_path<RtCfgV2>(sc, f, px, py, s, stk, sum, segs); break;
+#ifdef ORC_STATIC_CASES
+                        ORC_STATIC_CASES
+#endif
                         default: run_path<RtCfgV3>(sc, f, px, py, s, stk, sum, segs); break;
                     }
                 }
@@ -110,6 +120,14 @@ int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint
     return bad.load() ? -2 : 0;
 }
 
+/* number of compile-time topologies built in as variants 100.. (0 in the ordinary build) */
+int orcflat_n_static(void) {
+#ifdef ORC_N_STATIC
+    return ORC_N_STATIC;
+#else
+    return 0;
+#endif
+}
 uint64_t orcflat_item_count(const RtFrame* f) { return rt_item_count(*f); }
 void orcflat_item_decode(const RtFrame* f, uint64_t item, uint32_t out[3]) { rt_item_decode(*f, item, out[0], out[1], out[2]); }
 uint32_t orcflat_sizeof(int what) {

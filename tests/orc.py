@@ -98,8 +98,14 @@ B.orcflat_item_count.argtypes = [C.POINTER(Frame)]
 B.orcflat_item_decode.argtypes = [C.POINTER(Frame), C.c_uint64, _P]
 
 
+def declare_flat(lib):
+    lib.orcflat_render.restype = C.c_int
+    lib.orcflat_render.argtypes = B.orcflat_render.argtypes
+    return lib
+
+
 def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-                threads=None, variant=None):
+                threads=None, variant=None, lib=None):
     """CPU build of the kernel core over the flat arrays of a committed rt1w scene.
     `variant`: kernel variant (0..3, see rt_flat.h); default = the one the library picks."""
     x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
@@ -115,7 +121,7 @@ def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offse
     mx = C.c_uint32()
     threads = threads or min(16, os.cpu_count() or 1)
     ptr = [a.ctypes.data_as(_P) for a in arrs]
-    rc = B.orcflat_render(ptr[0], info["n_nodes"], ptr[1], info["n_lights"], ptr[2], info["n_materials"], ptr[3],
+    rc = (lib or B).orcflat_render(ptr[0], info["n_nodes"], ptr[1], info["n_lights"], ptr[2], info["n_materials"], ptr[3],
                           info["n_textures"], ptr[4], ptr[5], ptr[6], C.byref(f), variant, 1 if out_sum else 0, threads,
                           out.ctypes.data_as(_P), C.byref(seg), C.byref(mx))
     assert rc == 0, "flat core reported a traversal stack overflow"
