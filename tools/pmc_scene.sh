@@ -16,7 +16,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "rt_render_kernel" in r["Kernel_Name"]:
+        if "rt_render_kernel" in r["Kernel_Name"] or "rt_jit_sorted" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
     for k, v in sorted(agg.items()):
