@@ -291,7 +291,7 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
                          double t, RtHit& h) {
     const RtNode* nodes = sc.nodes;
     const RtNode& nd = nodes[prim];
-    bool want_uv = Cfg::tex && (sc.materials[nd.mat].kind & RT_MAT_NEEDS_UV) != 0u;
+    bool want_uv = Cfg::tex && (RT_MAT_KINDF(nd.mat) & RT_MAT_NEEDS_UV) != 0u;
     RtRayOD r0; r0.o = world.o; r0.d = world.d;
     if (scope == RT_NONE) {
         rt_leaf_record<Cfg>(nd, r0, world.time, t, want_uv, h);
@@ -731,6 +731,13 @@ RT_HD RtV3 rt_texture(const RtSceneView& sc, uint32_t tex, double u, double v, R
     }
 }
 
+/* texture.value(u, v, p) of a material: a SolidColor's value is kept in the material record itself */
+template <class Cfg>
+RT_HD RtV3 rt_mat_colour(const RtSceneView& sc, const RtMaterial& m, double u, double v, RtV3 p) {
+    if (!Cfg::tex || (m.kind & RT_MAT_SOLID) != 0u) return rt_v3(m.d[0], m.d[1], m.d[2]);
+    return rt_texture<Cfg>(sc, m.tex, u, v, p);
+}
+
 /* ------------------------------------------------------------ samplers -- */
 
 /* math.rs:6-18 */
@@ -902,7 +909,7 @@ RT_HD RtTrace rt_path_trace(const RtSceneView& sc, const NS& ns, RtPath& p, Stac
     if (p.depth_left == 0u) return tr;
     bool found = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, tr.t, tr.prim, tr.scope);
     if (!found) { tr.prim = RT_NONE; return tr; }
-    uint32_t mk = sc.materials[ns.hot(tr.prim).mat].kind & 0xFFu;
+    uint32_t mk = RT_MAT_KINDF(ns.hot(tr.prim).mat) & 0xFFu; /* the node carries its material's kind word */
     tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT
            : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
            : mk == RT_MAT_METAL ? RT_CLS_METAL
@@ -932,8 +939,8 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
     RtHit h;
     rt_finish_hit<Cfg>(sc, p.ray, prim, scope, t, h);
     RT_STAMP(3);
-    const RtMaterial& m = sc.materials[h.mat];
-    uint32_t mk = m.kind & 0xFFu;
+    const RtMaterial& m = sc.materials[RT_MAT_INDEX(h.mat)];
+    uint32_t mk = RT_MAT_KINDF(h.mat) & 0xFFu;
     RT_STAT_MAT(mk);
 
     /* emitted: DiffuseLight material.rs:168-181 (front face only); every other
@@ -942,7 +949,7 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
      * emitting material never scatters, so a path's radiance is beta (.) its
      * terminal value (light, background, or the zero of depth exhaustion). */
     if (mk == RT_MAT_DIFFUSE_LIGHT) {
-        RtV3 emitted = h.front ? rt_texture<Cfg>(sc, m.tex, h.u, h.v, h.p) : rt_v3(0.0, 0.0, 0.0);
+        RtV3 emitted = h.front ? rt_mat_colour<Cfg>(sc, m, h.u, h.v, h.p) : rt_v3(0.0, 0.0, 0.0);
         p.radiance = p.radiance + rt_mul(p.beta, emitted);
         p.alive = false; /* DiffuseLight::scatter -> None, main.rs:110-112 */
         return;
@@ -950,7 +957,7 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
 
     if (mk == RT_MAT_LAMBERTIAN) {
         /* Lambertian::scatter material.rs:71-80 -> ScatterKind::Pdf(CosinePdf) */
-        RtV3 attenuation = rt_texture<Cfg>(sc, m.tex, h.u, h.v, h.p);
+        RtV3 attenuation = rt_mat_colour<Cfg>(sc, m, h.u, h.v, h.p);
         RtOnb uvw = rt_onb_from_w(h.n);
         RtV3 dir;
         double pdf;
@@ -1040,7 +1047,7 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
         p.ray.o = h.p; p.ray.d = dir;
     } else if (Cfg::media && mk == RT_MAT_ISOTROPIC) {
         /* Isotropic::scatter constant_medium.rs:37-50 */
-        RtV3 attenuation = rt_texture<Cfg>(sc, m.tex, h.u, h.v, h.p);
+        RtV3 attenuation = rt_mat_colour<Cfg>(sc, m, h.u, h.v, h.p);
         RtV3 dir = rt_random_in_unit_sphere(p.rng);
         p.beta = rt_mul(p.beta, attenuation);
         p.ray.o = h.p; p.ray.d = dir;

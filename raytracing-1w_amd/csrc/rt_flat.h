@@ -70,10 +70,15 @@ enum {
     RT_MAT_ISOTROPIC = 5     /* src/constant_medium.rs:31-51 tex */
 };
 #define RT_MAT_NEEDS_UV 0x100u /* texture tree of this material reads (u,v): image texture */
+#define RT_MAT_SOLID 0x200u    /* the material's texture is a SolidColor and its colour is also in d[0..2] */
+/* a node's `mat` = material index in the low 16 bits, that material's kind word (kind | flags) above: the path class of a
+ * hit and the u,v question are answered by the node record alone, without a dependent fetch of the material */
+#define RT_MAT_INDEX(m) ((m) & 0xFFFFu)
+#define RT_MAT_KINDF(m) ((m) >> 16)
 
 struct RtMaterial {
     double d[4];
-    uint32_t kind; /* low 8 bits kind, RT_MAT_NEEDS_UV flag */
+    uint32_t kind; /* low 8 bits kind, RT_MAT_NEEDS_UV / RT_MAT_SOLID flags */
     uint32_t tex;
     uint32_t pad0, pad1;
 }; /* 48 bytes */

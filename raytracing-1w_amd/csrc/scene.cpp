@@ -568,7 +568,13 @@ int rt1w_scene_commit(rt1w_scene* s) {
         uint32_t k = m.kind & 0xFFu;
         bool has_tex = (k == RT_MAT_LAMBERTIAN || k == RT_MAT_DIFFUSE_LIGHT || k == RT_MAT_ISOTROPIC);
         m.kind = k | ((has_tex && texture_needs_uv(*s, m.tex)) ? RT_MAT_NEEDS_UV : 0u);
+        if (has_tex && s->textures[m.tex].kind == RT_TEX_SOLID) { /* SolidColor::value texture.rs:26-28: the colour, whatever u,v,p */
+            const RtTexture& t = s->textures[m.tex];
+            m.d[0] = t.d[0]; m.d[1] = t.d[1]; m.d[2] = t.d[2];
+            m.kind |= RT_MAT_SOLID;
+        }
     }
+    if (s->materials.size() > 0xFFFFu) { set_error("more than 65535 materials"); return RT1W_ERR_UNSUPPORTED; }
     s->flat_nodes.clear();
     Flattener f{*s, s->flat_nodes};
     uint32_t need = 0;
@@ -591,6 +597,10 @@ int rt1w_scene_commit(rt1w_scene* s) {
             if (k == RT_BVH2 && (N[i].a != i + 1 || N[i].b != N[N[i].a].skip)) { set_error("internal: nodes not in pre-order"); return RT1W_ERR_INVALID; }
             if ((k == RT_BVH1 || (k >= RT_TRANSLATE && k <= RT_MEDIUM)) && N[i].a != i + 1) { set_error("internal: nodes not in pre-order"); return RT1W_ERR_INVALID; }
         }
+    }
+    for (RtNode& n : s->flat_nodes) {
+        uint32_t k = n.kind & RT_KIND_MASK;
+        if ((k >= RT_SPHERE && k <= RT_YZ) || k == RT_MEDIUM) n.mat = n.mat | (s->materials[n.mat].kind << 16);
     }
     s->flat_root = root;
     s->stack_need = 1u + need;
