@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,8 @@ std::string jit_key(const std::string& source) {
 }
 
 int jit_compile(const std::string& source, std::vector<char>& code, std::string& log) {
+    static std::mutex mu; /* one compile at a time per process (contexts may be created from several host threads) */
+    std::lock_guard<std::mutex> lock(mu);
     std::string err;
     if (!load_hiprtc(err)) { log = err; return RT1W_ERR_UNSUPPORTED; }
     hiprtcProgram prog = nullptr;

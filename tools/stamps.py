@@ -9,9 +9,9 @@ names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+t
 for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), (400, 400, 32)) for a in sys.argv[1:]):
     sc = rt.Scene.reference(arm)
     ctx = rt.Context(sc, 0)
-    ctx.render(W, H, 2)
+    ctx.render(W, H, 2, generic=True)
     ctx.debug_stamps(True)
-    g, s = ctx.render(W, H, spp)
+    g, s = ctx.render(W, H, spp, generic=True)   # the stamps are in the library's own (generic) kernels
     rc, st = ctx.debug_stamps(True)
     tot = sum(st)
     print(f"arm {arm} variant {s['variant']} kernel_ms {s['kernel_ms']:.1f} segments {s['segments']} stamps_valid {rc}")
