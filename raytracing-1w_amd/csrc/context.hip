@@ -28,25 +28,6 @@
 #include <vector>
 
 #include "rt1w.h"
-#ifdef RT_STAMPS
-/* DIAGNOSTIC BUILD (librt1w_stamps.so): per-wave cycle accounting by phase.  Buckets:
- * 0 loop/other, 1 regeneration (new sample / new work item), 2 traversal, 3 hit record,
- * 4 lambertian shading, 5 other shading, 6 sample bookkeeping.  Stamp values go only to
- * g_stamp_total, which no render code reads. */
-__shared__ unsigned long long rt_stamp_acc[4][16];
-__shared__ unsigned long long rt_stamp_last[4];
-__device__ unsigned long long g_stamp_total[16];
-__device__ __forceinline__ void rt_stamp_fn(int k) {
-    unsigned long long t = __builtin_amdgcn_s_memtime();
-    unsigned long long m = __ballot(1);
-    if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) {
-        int w = threadIdx.x >> 6;
-        rt_stamp_acc[w][k] += t - rt_stamp_last[w];
-        rt_stamp_last[w] = t;
-    }
-}
-#define RT_STAMP(k) rt_stamp_fn(k)
-#endif
 #include "rt_kernel_sorted.h"
 #include "scene.h"
 #include "jit.h"
@@ -763,18 +744,31 @@ int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* ou
 
 int rt1w_debug_stamps(rt1w_context* c, uint64_t out[16], int reset) {
     if (!c || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
-#ifdef RT_STAMPS
-    (void)hipSetDevice(c->device);
-    unsigned long long h[16];
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp_total), sizeof h);
-    for (int i = 0; i < 16; ++i) out[i] = h[i];
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_total), z, sizeof z); }
-    return 1;
-#else
-    (void)reset;
     for (int i = 0; i < 16; ++i) out[i] = 0;
-    return 0;
+    int valid = 0;
+    (void)hipSetDevice(c->device);
+#ifdef RT_STAMPS
+    {
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp_total), sizeof h);
+        for (int i = 0; i < 16; ++i) out[i] += h[i];
+        if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_total), z, sizeof z); }
+        valid = 1;
+    }
 #endif
+    /* a scene-specialised kernel compiled with RT1W_JIT_STAMPS=1 in the environment carries its own counters */
+    if (c->jit_mod) {
+        hipDeviceptr_t dptr = nullptr;
+        size_t bytes = 0;
+        if (hipModuleGetGlobal(&dptr, &bytes, c->jit_mod, "g_stamp_total") == hipSuccess && bytes == 16 * sizeof(unsigned long long)) {
+            unsigned long long h[16];
+            (void)hipMemcpy(h, dptr, sizeof h, hipMemcpyDeviceToHost);
+            for (int i = 0; i < 16; ++i) out[i] += h[i];
+            if (reset) (void)hipMemset(dptr, 0, sizeof h);
+            valid = 1;
+        }
+    }
+    return valid;
 }
 
 int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, double* out, uint64_t n) {

@@ -74,8 +74,10 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
 }
 uint64_t fnv1a(uint64_t h, const std::string& s) { return fnv1a(h, s.data(), s.size()); }
 
-const char* const kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1"};
-const int kNumOptions = (int)(sizeof kOptions / sizeof kOptions[0]);
+const char* const kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1", "-DRT_STAMPS=1"};
+/* the last option only with RT1W_JIT_STAMPS in the environment: per-phase cycle counters (diagnostics, tools/stamps.py) */
+int n_options() { return (int)(sizeof kOptions / sizeof kOptions[0]) - (std::getenv("RT1W_JIT_STAMPS") ? 0 : 1); }
+#define kNumOptions n_options()
 
 bool read_file(const std::string& path, std::vector<char>& out) {
     FILE* f = std::fopen(path.c_str(), "rb");

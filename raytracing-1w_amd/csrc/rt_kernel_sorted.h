@@ -3,6 +3,25 @@
 #ifndef RT_KERNEL_SORTED_H
 #define RT_KERNEL_SORTED_H
 
+#ifdef RT_STAMPS
+/* DIAGNOSTIC BUILDS (librt1w_stamps.so; specialised kernels compiled with RT1W_JIT_STAMPS=1): per-wave cycle accounting by phase.  Buckets:
+ * 0 loop/other, 1 regeneration (new sample / new work item), 2 traversal, 3 hit record,
+ * 4 lambertian shading, 5 other shading, 6 sample bookkeeping.  Stamp values go only to
+ * g_stamp_total, which no render code reads. */
+__shared__ unsigned long long rt_stamp_acc[4][16];
+__shared__ unsigned long long rt_stamp_last[4];
+__device__ unsigned long long g_stamp_total[16];
+__device__ __forceinline__ void rt_stamp_fn(int k) {
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) {
+        int w = threadIdx.x >> 6;
+        rt_stamp_acc[w][k] += t - rt_stamp_last[w];
+        rt_stamp_last[w] = t;
+    }
+}
+#define RT_STAMP(k) rt_stamp_fn(k)
+#endif
 #include "rt_core.h"
 
 #define RT_BLOCK 256
@@ -118,7 +137,9 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
             if (tr.cls == c) my_rank = lane_prefix(m);
             if (lane == 0u) cnt[wave][c] = (uint32_t)__popcll(m);
         }
+        RT_STAMP(8);
         __syncthreads();
+        RT_STAMP(9);
         uint32_t dest = my_rank, idle_total = 0;
 #pragma unroll
         for (uint32_t c = 0; c < RT_N_CLS; ++c) {
@@ -152,7 +173,9 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
 #undef RT_PUTD
 #undef RT_PUT2
         }
+        RT_STAMP(10);
         __syncthreads();
+        RT_STAMP(11);
         {
             const unsigned long long* q = xch + threadIdx.x;
             unsigned long long v_;

@@ -1,19 +1,30 @@
-"""Per-phase cycle shares of the render kernel (diagnostic build librt1w_stamps.so)."""
+"""Per-phase cycle shares of the reordering render kernel.
+  python tools/stamps.py [arms...]        generic kernels of the diagnostic build librt1w_stamps.so (make -C raytracing-1w_amd/csrc stamps)
+  python tools/stamps.py --jit [arms...]  the scene-specialised kernel, compiled here with the counters in (RT1W_JIT_STAMPS=1)"""
 import os, sys
-os.environ["RT1W_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracing-1w_amd", "librt1w_stamps.so")
-import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+args = sys.argv[1:]
+jit = "--jit" in args
+args = [a for a in args if a != "--jit"]
+if jit:
+    os.environ["RT1W_JIT_STAMPS"] = "1"
+    os.environ.setdefault("RT1W_KERNEL_CACHE", "/tmp/rt1w_stamps_cache")
+else:
+    os.environ["RT1W_LIB"] = os.path.join(ROOT, "raytracing-1w_amd", "librt1w_stamps.so")
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc
 rt = orc.rt()
-names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+tail", "loop top", "sort+exchange+barriers", "sweep setup", "sweep pop+hdr", "sweep idle step", "sweep bvh step", "sweep prim step", "sweep scope step", "-", "-"]
-for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), (400, 400, 32)) for a in sys.argv[1:]):
+names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+tail", "loop top", "exchange: read", "sort: ballots+counts", "sort: barrier 1 wait", "exchange: rank+write", "exchange: barrier 2 wait", "-", "-", "-", "-"]
+for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), (400, 400, 32)) for a in args):
     sc = rt.Scene.reference(arm)
     ctx = rt.Context(sc, 0)
-    ctx.render(W, H, 2, generic=True)
+    if jit:
+        print("specialise:", ctx.specialise())
+    ctx.render(W, H, 2, generic=not jit)
     ctx.debug_stamps(True)
-    g, s = ctx.render(W, H, spp, generic=True)   # the stamps are in the library's own (generic) kernels
+    g, s = ctx.render(W, H, spp, generic=not jit)
     rc, st = ctx.debug_stamps(True)
     tot = sum(st)
-    print(f"arm {arm} variant {s['variant']} kernel_ms {s['kernel_ms']:.1f} segments {s['segments']} stamps_valid {rc}")
+    print(f"arm {arm} variant {s['variant']} sorted {s['sorted']} kernel_ms {s['kernel_ms']:.1f} segments {s['segments']} stamps_valid {rc}")
     for n, v in zip(names, st):
-        if v: print(f"  {n:14s} {100.0*v/tot:5.1f}%   cycles/segment/wave {v/(s['segments']/64):8.1f}")
+        if v: print(f"  {n:24s} {100.0*v/tot:5.1f}%   cycles/segment/wave {v/(s['segments']/64):8.1f}")
