@@ -1,0 +1,22 @@
+#!/bin/bash
+# instruction-cache counters of the Cornell render (quick_bench arm 5): tools/pmc_icache.sh <tag>
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmci_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for ctrs in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/quick_bench.py 5 > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(list)
+for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        if "rt_render_kernel" in r["Kernel_Name"] or "rt_jit_sorted" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    v = v[1:] if len(v) > 1 else v
+    print(f"{k:32s} launches={len(v):3d} mean_per_launch={sum(v)/len(v):.6g}")
+PY
