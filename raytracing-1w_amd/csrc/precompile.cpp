@@ -3,8 +3,11 @@
  * renders never meet the run-time compiler.  No GPU needed (hiprtc cross-compiles for gfx950).
  *   rt1w_precompile <out_dir> [build_seed ...]
  */
+#include <dirent.h>
+
 #include <cstdio>
 #include <cstdlib>
+#include <set>
 #include <string>
 
 #include "jit.h"
@@ -13,6 +16,7 @@ int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: rt1w_precompile <out_dir> [build_seed ...]\n"); return 2; }
     const std::string dir = argv[1];
     int failures = 0;
+    std::set<std::string> keep;
     for (int a = 2; a < (argc > 2 ? argc : 3); ++a) {
         unsigned long long seed = argc > 2 ? std::strtoull(argv[a], nullptr, 10) : 1ull;
         for (int arm = 0; arm < 8; ++arm) {
@@ -27,11 +31,20 @@ int main(int argc, char** argv) {
                 rt1w::JitInfo info;
                 int rc = rt1w::jit_precompile_to(*s, dir, info);
                 if (rc < 0) { std::fprintf(stderr, "arm %d seed %llu: %s\n", arm, seed, info.message.c_str()); ++failures; }
-                else std::printf("arm %d seed %llu: %zu nodes -> %s (%s, %.1f s)\n", arm, seed, s->flat_nodes.size(), info.path.c_str(),
+                else keep.insert(info.path.substr(info.path.rfind('/') + 1));
+                if (rc >= 0) std::printf("arm %d seed %llu: %zu nodes -> %s (%s, %.1f s)\n", arm, seed, s->flat_nodes.size(), info.path.c_str(),
                                  info.from_cache ? "present" : "compiled", info.compile_ms / 1e3);
             }
             rt1w_scene_destroy(s);
         }
+    }
+    /* kernels of earlier builds (other header text = other key) are dead weight: drop them */
+    if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* e = readdir(d)) {
+            std::string n = e->d_name;
+            if (n.rfind("sweep_", 0) == 0 && n.size() > 6 && n.substr(n.size() - 6) == ".hsaco" && !keep.count(n)) std::remove((dir + "/" + n).c_str());
+        }
+        closedir(d);
     }
     return failures ? 1 : 0;
 }
