@@ -410,55 +410,76 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
                              uint32_t& out_scope);
 
-/* one stack entry.  MEDIA=false is the flavour used for a ConstantMedium's boundary, where only t is
- * consumed (constant_medium.rs:62-69). */
-template <class Cfg, bool MEDIA, class Stack, class NS>
-RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
+/* The walk's work, one piece per kind of stack entry (MEDIA=false is the flavour used for a ConstantMedium's
+ * boundary, where only t is consumed, constant_medium.rs:62-69). */
+enum { RT_WK_NONE = 0, RT_WK_BOX = 1, RT_WK_LEAF = 2, RT_WK_WRAP = 3, RT_WK_EXIT = 4, RT_WK_OTHER = 5 };
+RT_HD uint32_t rt_walk_class(uint32_t kind) {
+    return kind <= RT_BVH1 ? RT_WK_BOX : (kind <= RT_YZ ? RT_WK_LEAF : (kind <= RT_FLIP ? RT_WK_WRAP : RT_WK_OTHER));
+}
+/* leaving a wrapper: back to the parent's ray (recomputed from the outer ray by the same operations that
+ * produced it, hence the same bits) */
+RT_HD void rt_walk_exit(const RtSceneView& sc, RtWalk& k, uint32_t e) {
     const RtNode* nodes = sc.nodes;
-    uint32_t e = stk.pop();
-    if (e & RT_POP_FLAG) {
-        /* leaving a wrapper: back to the parent's ray (recomputed from the outer ray by the
-         * same operations that produced it, hence the same bits) */
-        k.scope = nodes[e & ~RT_POP_FLAG].b;
-        if (k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
-        else { k.cur = rt_ray_in_scope(nodes, k.scope, k.w); k.inv = rt_inv3(k.cur.d); }
-        return;
+    k.scope = nodes[e & ~RT_POP_FLAG].b;
+    if (k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
+    else { k.cur = rt_ray_in_scope(nodes, k.scope, k.w); k.inv = rt_inv3(k.cur.d); }
+}
+template <class Stack>
+RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
+    bool hit;
+    if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+    else hit = rt_aabb_hit_fast(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+    if (hit) {
+        if ((nd.kind & RT_KIND_MASK) == RT_BVH2) stk.push(nd.b);
+        stk.push(e + 1u); /* left child / only child: the next node in pre-order */
     }
-    const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
-    uint32_t kind = nd.kind & RT_KIND_MASK;
-    RT_STAT_VISIT(kind);
-    if (kind <= RT_BVH1) {
-        bool hit;
-        if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
-        else hit = rt_aabb_hit_fast(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
-        if (hit) {
-            if (kind == RT_BVH2) stk.push(nd.b);
-            stk.push(e + 1u); /* left child / only child: the next node in pre-order */
-        }
-    } else if (kind <= RT_YZ) {
-        double t;
-        bool hit;
-        if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(nodes[e], kind, k.cur.o, k.cur.d, k.time, k.t_min, k.best_t, t);
-        else hit = rt_prim_hot_sel_t(nd, kind, k.cur.o, k.cur.d, k.t_min, k.best_t, t);
-        if (hit) { k.best_t = t; k.best_prim = e; k.best_scope = k.scope; }
-    } else if (kind <= RT_FLIP) {
-        stk.push(e | RT_POP_FLAG);
-        k.scope = e;
-        if (kind != RT_FLIP) {
-            k.cur = rt_scope_in(nd, k.cur);
-            if (kind == RT_ROTATE_Y) k.inv = rt_inv3(k.cur.d);
-        }
-        stk.push(e + 1u);
-    } else if (MEDIA && Cfg::media && kind == RT_MEDIUM) {
+}
+template <class Cfg>
+RT_HD void rt_walk_leaf(const RtSceneView& sc, RtWalk& k, uint32_t e, const RtNodeHot& nd) {
+    const uint32_t kind = nd.kind & RT_KIND_MASK;
+    double t;
+    bool hit;
+    if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(sc.nodes[e], kind, k.cur.o, k.cur.d, k.time, k.t_min, k.best_t, t);
+    else hit = rt_prim_hot_sel_t(nd, kind, k.cur.o, k.cur.d, k.t_min, k.best_t, t);
+    if (hit) { k.best_t = t; k.best_prim = e; k.best_scope = k.scope; }
+}
+template <class Stack>
+RT_HD void rt_walk_wrap(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
+    const uint32_t kind = nd.kind & RT_KIND_MASK;
+    stk.push(e | RT_POP_FLAG);
+    k.scope = e;
+    if (kind != RT_FLIP) {
+        k.cur = rt_scope_in(nd, k.cur);
+        if (kind == RT_ROTATE_Y) k.inv = rt_inv3(k.cur.d);
+    }
+    stk.push(e + 1u);
+}
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_t e, const RtNodeHot& nd, RtRng& rng, Stack& stk) {
+    if (MEDIA && Cfg::media && (nd.kind & RT_KIND_MASK) == RT_MEDIUM) {
         /* ConstantMedium::hit constant_medium.rs:58-113: two complete boundary walks, then the free-flight draw */
         RtRay br; br.o = k.cur.o; br.d = k.cur.d; br.time = k.time;
         double t1, t2, t; uint32_t p_, s_;
         if (rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_) &&
             rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_) &&
-            rt_medium_t(nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
+            rt_medium_t(sc.nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
             k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
         }
     }
+}
+
+/* one stack entry */
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
+    uint32_t e = stk.pop();
+    if (e & RT_POP_FLAG) { rt_walk_exit(sc, k, e); return; }
+    const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
+    const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
+    RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
+    if (cls == RT_WK_BOX) rt_walk_box(k, e, nd, stk);
+    else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg>(sc, k, e, nd);
+    else if (cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk);
+    else rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
 }
 
 template <class Cfg, bool MEDIA, class Stack, class NS>
