@@ -221,6 +221,9 @@ typedef struct rt1w_specialise_info {
     uint32_t grid, vgprs;/* persistent grid of the kernel; 0 if unknown */
 } rt1w_specialise_info;
 int rt1w_context_specialise(rt1w_context* c, uint32_t flags, rt1w_specialise_info* info /* may be NULL */);
+/* cache key of the specialised kernel of a committed scene (16 hex digits + NUL): the code object is
+ * `sweep_<key>.hsaco` in the kernel cache.  No GPU needed.  RT1W_ERR_UNSUPPORTED for scenes of more than 64 nodes. */
+int rt1w_scene_kernel_key(const rt1w_scene* s, char out[24]);
 
 /* ---- output side (src/color.rs) ---- */
 

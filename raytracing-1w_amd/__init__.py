@@ -119,6 +119,7 @@ _sig("rt1w_device_count", C.c_int)
 _sig("rt1w_context_create", C.c_int, C.c_int, _P, C.POINTER(_P))
 _sig("rt1w_context_destroy", None, _P)
 _sig("rt1w_context_specialise", C.c_int, _P, C.c_uint32, C.POINTER(SpecialiseInfo))
+_sig("rt1w_scene_kernel_key", C.c_int, _P, C.c_char * 24)
 _sig("rt1w_default_chunk", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("rt1w_render", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
@@ -281,6 +282,12 @@ class Scene:
         i = SceneInfo()
         _ck(_lib.rt1w_scene_get_info(self._h, C.byref(i)))
         return {n: getattr(i, n) for n, _ in SceneInfo._fields_}
+
+    def kernel_key(self):
+        """Cache key of this scene's specialised kernel (sweep_<key>.hsaco); raises ERR_UNSUPPORTED for big scenes."""
+        buf = (C.c_char * 24)()
+        _ck(_lib.rt1w_scene_kernel_key(self._h, buf))
+        return buf.value.decode()
 
     def flat(self, what):
         """Bytes of one flat array (0 nodes,1 lights,2 materials,3 textures,4 perlin,5 images,6 camera+bg)."""

@@ -229,3 +229,11 @@ int jit_precompile_to(const rt1w_scene& s, const std::string& dir, JitInfo& info
 }
 
 } // namespace rt1w
+
+extern "C" int rt1w_scene_kernel_key(const rt1w_scene* s, char out[24]) {
+    if (!s || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { rt1w::set_error("scene not committed"); return RT1W_ERR_STATE; }
+    if (!rt1w::jit_eligible(*s)) { rt1w::set_error("scene has more than RT_SWEEP_MAX_NODES nodes: no specialised kernel"); return RT1W_ERR_UNSUPPORTED; }
+    std::snprintf(out, 24, "%s", rt1w::jit_key(rt1w::jit_source(*s)).c_str());
+    return RT1W_OK;
+}

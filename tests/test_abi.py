@@ -130,3 +130,26 @@ def test_format_ppm_matches_reference_layout(rt):
     lines = txt.split("\n")
     assert lines[:3] == ["P3", "3 2", "255"]
     assert lines[3] == "255 128 0" and lines[4] == "0 0 0" and len(lines) == 3 + 6 + 1 and lines[-1] == ""
+
+
+def test_specialised_kernels_of_the_reference_arms_are_built(rt):
+    """Host side of the scene-specialised kernels (jit.cpp), no GPU: the cache key is a function of the scene's
+    topology and of the library's own source; the build has compiled the reference's eligible arms (build_seed 1)
+    into <package>/kernels; big scenes are refused."""
+    import os
+    kdir = os.path.join(os.path.dirname(rt.LIB_PATH), "kernels")
+    keys = {}
+    for arm in (1, 2, 3, 4, 5, 6):
+        key = rt.Scene.reference(arm, build_seed=1).kernel_key()
+        assert len(key) == 16 and int(key, 16) >= 0
+        path = os.path.join(kdir, f"sweep_{key}.hsaco")
+        assert os.path.exists(path), f"arm {arm}: {path} missing -- run the build (make -C raytracing-1w_amd/csrc)"
+        assert open(path, "rb").read(4) == b"\x7fELF"
+        keys[arm] = key
+    assert keys[5] != keys[6] and keys[5] != keys[4]
+    assert rt.Scene.reference(5, build_seed=1).kernel_key() == keys[5]          # deterministic
+    assert rt.Scene.reference(5, build_seed=2).kernel_key() != keys[5]          # another tree, another kernel
+    for arm in (0, 7):
+        with pytest.raises(rt.Rt1wError) as e:
+            rt.Scene.reference(arm, build_seed=1).kernel_key()
+        assert e.value.code == rt.ERR_UNSUPPORTED
