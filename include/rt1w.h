@@ -203,15 +203,16 @@ int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t stri
                      rt1w_progress_fn progress, void* user, rt1w_stats* stats);
 
 /* ---- scene-specialised kernels ----
- * Scenes of up to 64 flattened nodes (Cornell: 29) are traversed by a stackless pre-order sweep.  When the node kinds
- * and subtree ends are compile-time constants that sweep unrolls into straight-line code along the scene's own tree
- * (about 15 % faster on the Cornell box; same arithmetic, bit-identical frames).  The constants are only known once a
- * scene is committed, so such a kernel is generated per scene topology and compiled with hiprtc (3-5 s), then kept in a
- * kernel cache: <directory of librt1w.so>/kernels (filled by the build for the reference's own scene arms) and
- * $RT1W_KERNEL_CACHE or ~/.cache/rt1w.  rt1w_context_create looks the scene up in the cache and uses a hit silently;
- * rt1w_context_specialise compiles on a miss.  A render of >= 2^35 paths compiles on its own (the compile then costs
- * less than it saves) unless RT1W_NO_JIT is set in the environment.  Larger scenes keep the generic kernels:
- * RT1W_ERR_UNSUPPORTED.  RT1W_GENERIC in rt1w_render_params.flags selects the generic kernel for one render. */
+ * Small scenes are traversed by a stackless pre-order sweep.  When the node kinds and subtree ends are compile-time
+ * constants that sweep unrolls into straight-line code along the scene's own tree (same arithmetic, bit-identical
+ * frames; Cornell box, 29 nodes: 1.3x the generic sweep; scenes of 65-256 nodes: 1.5-2.3x the stack walk).  The constants
+ * are only known once a scene is committed, so such a kernel is generated per scene topology and compiled with hiprtc
+ * (1-8 s), then kept in a kernel cache: <directory of librt1w.so>/kernels (filled by the build for the reference's own
+ * scene arms) and $RT1W_KERNEL_CACHE or ~/.cache/rt1w.  rt1w_context_create looks the scene up in the cache and uses a
+ * hit silently; rt1w_context_specialise compiles on a miss.  A render of >= 2^35 paths compiles on its own (the compile
+ * then costs less than it saves) unless RT1W_NO_JIT is set in the environment.  Scenes of more than 256 nodes keep the
+ * generic kernels: RT1W_ERR_UNSUPPORTED.  RT1W_GENERIC in rt1w_render_params.flags selects the generic kernel for one
+ * render. */
 #define RT1W_SPECIALISE_CACHED_ONLY 1u /* do not run the compiler: RT1W_ERR_STATE on a cache miss */
 typedef struct rt1w_specialise_info {
     char key[24];        /* cache key: hash of the generated source, the library's embedded headers and the compiler options */
@@ -222,7 +223,7 @@ typedef struct rt1w_specialise_info {
 } rt1w_specialise_info;
 int rt1w_context_specialise(rt1w_context* c, uint32_t flags, rt1w_specialise_info* info /* may be NULL */);
 /* cache key of the specialised kernel of a committed scene (16 hex digits + NUL): the code object is
- * `sweep_<key>.hsaco` in the kernel cache.  No GPU needed.  RT1W_ERR_UNSUPPORTED for scenes of more than 64 nodes. */
+ * `sweep_<key>.hsaco` in the kernel cache.  No GPU needed.  RT1W_ERR_UNSUPPORTED for scenes of more than 256 nodes. */
 int rt1w_scene_kernel_key(const rt1w_scene* s, char out[24]);
 
 /* ---- output side (src/color.rs) ---- */

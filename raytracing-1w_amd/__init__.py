@@ -323,7 +323,7 @@ class Context:
 
     def specialise(self, cached_only=False):
         """Load (from the kernel cache) or compile (hiprtc, 3-5 s) the kernel specialised for this scene's topology
-        (rt1w_context_specialise).  Returns the info dict; raises Rt1wError for scenes of more than 64 nodes
+        (rt1w_context_specialise).  Returns the info dict; raises Rt1wError for scenes of more than 256 nodes
         (ERR_UNSUPPORTED) or, with cached_only, on a cache miss (ERR_STATE)."""
         info = SpecialiseInfo()
         _ck(_lib.rt1w_context_specialise(self._h, SPECIALISE_CACHED_ONLY if cached_only else 0, C.byref(info)))

@@ -392,7 +392,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
 /* load the specialised kernel of this context's scene: from the caches, or (allow_compile) from the compiler */
 int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
     if (c->jit_fn) { info = rt1w::JitInfo(); info.key = c->jit_key; info.from_cache = true; return RT1W_OK; }
-    if (c->jit_src.empty()) { rt1w::set_error("scene has more than RT_SWEEP_MAX_NODES nodes: no specialised kernel"); return RT1W_ERR_UNSUPPORTED; }
+    if (c->jit_src.empty()) { rt1w::set_error("scene has more than RT_JIT_MAX_NODES nodes: no specialised kernel"); return RT1W_ERR_UNSUPPORTED; }
     std::vector<char> code;
     int rc = rt1w::jit_get_code(c->jit_src, allow_compile, code, info);
     c->jit_key = info.key;

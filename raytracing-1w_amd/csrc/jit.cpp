@@ -1,6 +1,6 @@
 /* jit.cpp -- topology-specialised render kernels, compiled at run time.
  *
- * For a scene of <= RT_SWEEP_MAX_NODES nodes the pre-order sweep can be unrolled along the scene's own
+ * For a scene of <= RT_JIT_MAX_NODES nodes the pre-order sweep can be unrolled along the scene's own
  * tree (rt_sweep_static in rt_core.h) once the node kinds and subtree ends are compile-time constants.
  * They are only known when a scene has been committed, so the kernel is generated then: this file writes
  * a ten-line translation unit (the topology as constexpr arrays + one extern "C" kernel around
@@ -126,7 +126,7 @@ std::string user_cache_dir() {
 } // namespace
 
 bool jit_eligible(const rt1w_scene& s) {
-    return s.committed && !s.flat_nodes.empty() && s.flat_nodes.size() <= RT_SWEEP_MAX_NODES;
+    return s.committed && !s.flat_nodes.empty() && s.flat_nodes.size() <= RT_JIT_MAX_NODES;
 }
 
 std::string jit_source(const rt1w_scene& s) {
@@ -188,7 +188,7 @@ int jit_compile(const std::string& source, std::vector<char>& code, std::string&
 
 int jit_get_code(const std::string& src, bool allow_compile, std::vector<char>& code, JitInfo& info) {
     info = JitInfo();
-    if (src.empty()) { info.message = "scene is not eligible (more than RT_SWEEP_MAX_NODES nodes)"; return RT1W_ERR_UNSUPPORTED; }
+    if (src.empty()) { info.message = "scene is not eligible (more than RT_JIT_MAX_NODES nodes)"; return RT1W_ERR_UNSUPPORTED; }
     info.key = jit_key(src);
     const std::string name = "/sweep_" + info.key + ".hsaco";
     const std::string dirs[2] = {install_cache_dir(), user_cache_dir()};
@@ -233,7 +233,7 @@ int jit_precompile_to(const rt1w_scene& s, const std::string& dir, JitInfo& info
 extern "C" int rt1w_scene_kernel_key(const rt1w_scene* s, char out[24]) {
     if (!s || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
     if (!s->committed) { rt1w::set_error("scene not committed"); return RT1W_ERR_STATE; }
-    if (!rt1w::jit_eligible(*s)) { rt1w::set_error("scene has more than RT_SWEEP_MAX_NODES nodes: no specialised kernel"); return RT1W_ERR_UNSUPPORTED; }
+    if (!rt1w::jit_eligible(*s)) { rt1w::set_error("scene has more than RT_JIT_MAX_NODES nodes: no specialised kernel"); return RT1W_ERR_UNSUPPORTED; }
     std::snprintf(out, 24, "%s", rt1w::jit_key(rt1w::jit_source(*s)).c_str());
     return RT1W_OK;
 }

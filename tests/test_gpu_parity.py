@@ -451,6 +451,31 @@ def test_scene_specialised_kernels_are_bit_identical(rt, gpu_ctx_factory, tmp_pa
         if done == 6:
             break
     assert done == 6
+    # (3b) a mid-size scene (Cornell walls + 8 rotated boxes = 141 nodes): the generic code is the stack walk, the specialised
+    #      kernel the unrolled sweep -- two different traversal implementations, same bits
+    s8 = rt.Scene(build_seed=1)
+    white = s8.lambertian(s8.solid_color((0.73, 0.73, 0.73))); lightm = s8.diffuse_light(s8.solid_color((15, 15, 15)))
+    objs = [s8.yz_rect(0, 555, 0, 555, 555, s8.lambertian(s8.solid_color((0.12, 0.45, 0.15)))),
+            s8.yz_rect(0, 555, 0, 555, 0, s8.lambertian(s8.solid_color((0.65, 0.05, 0.05)))),
+            s8.flip_face(s8.xz_rect(213, 343, 227, 332, 554, lightm)), s8.xz_rect(0, 555, 0, 555, 0, white),
+            s8.xz_rect(0, 555, 0, 555, 555, white), s8.xy_rect(0, 555, 0, 555, 555, white)]
+    g8 = np.random.default_rng(3)
+    for _ in range(8):
+        b = s8.aabox((0, 0, 0), (60, float(g8.uniform(60, 250)), 60), s8.metal((0.8, 0.85, 0.88), 0.1) if _ % 3 == 0 else white)
+        objs.append(s8.translate(s8.rotate_y(b, float(g8.uniform(-40, 40))), (float(g8.uniform(30, 460)), 0.0, float(g8.uniform(30, 460)))))
+    objs.append(s8.sphere((190, 90, 190), 40, s8.dielectric(1.5)))
+    s8.set_world(s8.bvh_node(objs))
+    s8.set_lights([s8.xz_rect(213, 343, 227, 332, 554, s8.null_material())])
+    s8.set_background((0, 0, 0))
+    s8.set_camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    s8.commit()
+    assert 64 < s8.info()["n_nodes"] <= 256
+    c8 = gpu_ctx_factory(s8)
+    gen8, sg8 = c8.render(120, 120, 12)
+    assert sg8["variant"] == 2 and not (sg8["sorted"] & 4)
+    c8.specialise()
+    spe8, ss8 = c8.render(120, 120, 12)
+    assert (ss8["sorted"] & 4) and ss8["segments"] == sg8["segments"] and np.array_equal(gen8, spe8, equal_nan=True)
     # (4) big scenes keep the generic kernels
     big = gpu_ctx_factory(rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5))
     with pytest.raises(rt.Rt1wError) as e:
