@@ -209,8 +209,8 @@ int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t stri
  * are only known once a scene is committed, so such a kernel is generated per scene topology and compiled with hiprtc
  * (1-8 s), then kept in a kernel cache: <directory of librt1w.so>/kernels (filled by the build for the reference's own
  * scene arms) and $RT1W_KERNEL_CACHE or ~/.cache/rt1w.  rt1w_context_create looks the scene up in the cache and uses a
- * hit silently; rt1w_context_specialise compiles on a miss.  A render of >= 2^35 paths compiles on its own (the compile
- * then costs less than it saves) unless RT1W_NO_JIT is set in the environment.  Scenes of more than 256 nodes keep the
+ * hit silently; rt1w_context_specialise compiles on a miss.  A render of >= 2^35 paths (2^32 for scenes of more than 64 nodes) compiles on
+ * its own -- the compile then costs less than it saves -- unless RT1W_NO_JIT is set in the environment.  Scenes of more than 256 nodes keep the
  * generic kernels: RT1W_ERR_UNSUPPORTED.  RT1W_GENERIC in rt1w_render_params.flags selects the generic kernel for one
  * render. */
 #define RT1W_SPECIALISE_CACHED_ONLY 1u /* do not run the compiler: RT1W_ERR_STATE on a cache miss */

@@ -415,9 +415,12 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
 }
 
 int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, rt1w_stats* stats) {
-    /* a render this long repays the 3-5 s of the compiler (RT1W_NO_JIT: never compile behind the caller's back) */
+    /* a render this long repays the 1-8 s of the compiler: 2^35 paths where the gain is ~1.3x (scenes the generic sweep
+     * handles), 2^32 where it is 1.5-2.3x (scenes the generic code hands to the stack walk).  RT1W_NO_JIT: never compile
+     * behind the caller's back */
     if (!c->jit_fn && !c->jit_failed && !c->jit_src.empty() && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) &&
-        (unsigned long long)p->tile_w * p->tile_h * p->spp >= (1ull << 35) && !getenv("RT1W_NO_JIT")) {
+        (unsigned long long)p->tile_w * p->tile_h * p->spp >= (c->n_nodes <= RT_SWEEP_MAX_NODES ? (1ull << 35) : (1ull << 32)) &&
+        !getenv("RT1W_NO_JIT")) {
         rt1w::JitInfo info;
         if (specialise(c, true, info) < 0) c->jit_failed = true;
     }
