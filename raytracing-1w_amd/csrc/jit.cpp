@@ -74,10 +74,21 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
 }
 uint64_t fnv1a(uint64_t h, const std::string& s) { return fnv1a(h, s.data(), s.size()); }
 
-const char* const kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1", "-DRT_STAMPS=1"};
-/* the last option only with RT1W_JIT_STAMPS in the environment: per-phase cycle counters (diagnostics, tools/stamps.py) */
-int n_options() { return (int)(sizeof kOptions / sizeof kOptions[0]) - (std::getenv("RT1W_JIT_STAMPS") ? 0 : 1); }
-#define kNumOptions n_options()
+/* compiler options: fixed, plus -DRT_STAMPS=1 with RT1W_JIT_STAMPS in the environment (per-phase cycle counters,
+ * tools/stamps.py), plus the space-separated words of RT1W_JIT_EXTRA_OPTS (compiler-flag experiments; never anything that
+ * changes floating-point semantics).  All of them go into the cache key. */
+std::vector<std::string> options() {
+    std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1"};
+    if (std::getenv("RT1W_JIT_STAMPS")) o.push_back("-DRT_STAMPS=1");
+    if (const char* e = std::getenv("RT1W_JIT_EXTRA_OPTS")) {
+        std::string w;
+        for (const char* p = e;; ++p) {
+            if (*p == ' ' || *p == 0) { if (!w.empty()) o.push_back(w); w.clear(); if (!*p) break; }
+            else w.push_back(*p);
+        }
+    }
+    return o;
+}
 
 bool read_file(const std::string& path, std::vector<char>& out) {
     FILE* f = std::fopen(path.c_str(), "rb");
@@ -156,7 +167,7 @@ std::string jit_key(const std::string& source) {
     uint64_t h = 0xcbf29ce484222325ull;
     h = fnv1a(h, source);
     for (int i = 0; i < RT_JIT_N_HEADERS; ++i) { h = fnv1a(h, rt_jit_header_names[i], std::strlen(rt_jit_header_names[i])); h = fnv1a(h, rt_jit_header_texts[i], std::strlen(rt_jit_header_texts[i])); }
-    for (int i = 0; i < kNumOptions; ++i) h = fnv1a(h, kOptions[i], std::strlen(kOptions[i]));
+    for (const std::string& o : options()) h = fnv1a(h, o);
     char buf[32];
     std::snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
     return buf;
@@ -171,7 +182,10 @@ int jit_compile(const std::string& source, std::vector<char>& code, std::string&
     if (g_rtc.CreateProgram(&prog, source.c_str(), "rt_jit_sorted.hip", RT_JIT_N_HEADERS, rt_jit_header_texts, rt_jit_header_names) != 0) {
         log = "hiprtcCreateProgram failed"; return RT1W_ERR_DEVICE;
     }
-    hiprtcResult rc = g_rtc.CompileProgram(prog, kNumOptions, kOptions);
+    const std::vector<std::string> opts = options();
+    std::vector<const char*> optv;
+    for (const std::string& o : opts) optv.push_back(o.c_str());
+    hiprtcResult rc = g_rtc.CompileProgram(prog, (int)optv.size(), optv.data());
     size_t ls = 0;
     g_rtc.GetProgramLogSize(prog, &ls);
     log.assign(ls, '\0');
