@@ -186,7 +186,8 @@ __global__ void rt_debug_aabb_kernel(const double* in, int* out_literal, int* ou
     RtV3 o = rt_v3(p[6], p[7], p[8]);
     RtV3 inv = rt_inv3(rt_v3(p[9], p[10], p[11]));
     out_literal[i] = rt_aabb_hit(p, o, inv, p[12], p[13]) ? 1 : 0;
-    out_fast[i] = rt_aabb_hit_fast(p, o, inv, p[12], p[13]) ? 1 : 0;
+    const bool fe = rt_aabb_hit_fast<true>(p, o, inv, p[12], p[13]), fn = rt_aabb_hit_fast<false>(p, o, inv, p[12], p[13]);
+    out_fast[i] = (fe == fn) ? (fe ? 1 : 0) : 2; /* 2: the two max/min forms disagree -- never equal to the literal's 0/1 */
 }
 
 __global__ void rt_debug_eval_kernel(int fn, const double* a, const double* b, double* out, unsigned long long n) {
