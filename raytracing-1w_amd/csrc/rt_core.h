@@ -320,13 +320,15 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
  * rt_prim_t).  `kind` is wave-uniform in the sweep, so the axis choice is a scalar branch. */
 RT_HD bool rt_rect_hot_t(const RtNodeHot& nd, double oa, double da, double ob, double db, double oc, double dc,
                          double t_min, double t_max, double& t_out) {
-    double t = (nd.d[4] - oa) / da;
-    if (t < t_min || t > t_max) return false;
-    double b = ob + t * db;
-    double c = oc + t * dc;
-    if (b < nd.d[0] || b > nd.d[1] || c < nd.d[2] || c > nd.d[3]) return false;
-    t_out = t;
-    return true;
+    /* both of aarect.rs' rejections as one conjunction (no exec-mask region for the second half: the wave runs it
+     * anyway unless every lane fails the first); a NaN passes each comparison exactly as it does there */
+    const double t = (nd.d[4] - oa) / da;
+    const bool in_t = !((t < t_min) | (t > t_max));
+    const double b = ob + t * db;
+    const double c = oc + t * dc;
+    const bool in_rect = !((b < nd.d[0]) | (b > nd.d[1]) | (c < nd.d[2]) | (c > nd.d[3]));
+    if (in_t & in_rect) { t_out = t; return true; }
+    return false;
 }
 RT_HD bool rt_prim_hot_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d, double t_min, double t_max, double& t_out) {
     if (kind == RT_XY) return rt_rect_hot_t(nd, o.z, d.z, o.x, d.x, o.y, d.y, t_min, t_max, t_out);
