@@ -36,6 +36,7 @@ def test_every_declared_entry_cites_the_reference():
 
 def test_struct_layouts_match_between_python_and_c(rt):
     assert C.sizeof(rt.RenderParams) == 48 and C.sizeof(rt.Stats) == 56 and C.sizeof(rt.SceneInfo) == 56
+    assert C.sizeof(rt.SpecialiseInfo) == 48
     assert orc.B.orcflat_sizeof(0) == 96 and orc.B.orcflat_sizeof(1) == 48 and orc.B.orcflat_sizeof(2) == 48
     assert orc.B.orcflat_sizeof(3) == 9216 and orc.B.orcflat_sizeof(5) == C.sizeof(orc.Frame)
 
