@@ -4,7 +4,9 @@
  * the literal `match 5`, main.rs:815); here the literals are options with the reference's
  * values as defaults.
  *   rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B]
- *        [--device I] [--earth file.rgb8 W H] [--out file.ppm]
+ *        [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic]
+ * --specialise compiles the kernel for this scene's topology now if the kernel cache has none (rt1w_context_specialise;
+ * by default only a cached kernel is used, and renders of >= 2^35 paths compile on their own); --generic forbids it.
  */
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,7 @@ static int fail(const char* what) {
 
 int main(int argc, char** argv) {
     int arm = 5, device = 0;
+    bool specialise = false, generic = false;
     long width = -1, height = -1, spp = -1, depth = 50; /* MAX_DEPTH main.rs:801 */
     unsigned long long build_seed = 1, seed = 0;
     std::string out_path, earth_path;
@@ -40,8 +43,10 @@ int main(int argc, char** argv) {
         else if (a == "--build-seed") build_seed = std::strtoull(next("--build-seed"), nullptr, 10);
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--out") out_path = next("--out");
+        else if (a == "--specialise") specialise = true;
+        else if (a == "--generic") generic = true;
         else if (a == "--earth") { earth_path = next("--earth"); earth_w = (unsigned)std::atoi(next("--earth W")); earth_h = (unsigned)std::atoi(next("--earth H")); }
-        else { std::fprintf(stderr, "usage: rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B] [--device I] [--earth file.rgb8 W H] [--out file.ppm]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B] [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic]\n"); return 2; }
     }
     std::vector<unsigned char> earth;
     if (!earth_path.empty()) {
@@ -66,10 +71,16 @@ int main(int argc, char** argv) {
     if (spp <= 0) spp = defaults[2];
     rt1w_context* ctx = nullptr;
     if (rt1w_context_create(device, scene, &ctx) < 0) return fail("context");
+    if (specialise && !generic) {
+        rt1w_specialise_info si;
+        if (rt1w_context_specialise(ctx, 0, &si) < 0) std::fprintf(stderr, "rt1w: not specialised: %s\n", rt1w_last_error());
+        else std::fprintf(stderr, "rt1w: kernel %s (%s, %.1f s in the compiler)\n", si.key, si.from_cache ? "from the kernel cache" : "compiled", si.compile_ms / 1e3);
+    }
     rt1w_render_params p;
     std::memset(&p, 0, sizeof p);
     p.width = (uint32_t)width; p.height = (uint32_t)height; p.tile_w = p.width; p.tile_h = p.height;
     p.spp = (uint32_t)spp; p.max_depth = (uint32_t)depth; p.global_seed = (uint32_t)seed;
+    if (generic) p.flags |= RT1W_GENERIC;
     /* the reference collects the rows top-down, counting them down on stderr (main.rs:957-960,995-998), then prints them
      * (main.rs:1003-1007); here the rows are quantised on the device and written as their strips land */
     std::vector<unsigned char> img((size_t)width * height * 3);
@@ -95,8 +106,8 @@ int main(int argc, char** argv) {
     rt1w_stats st;
     std::fprintf(stderr, "rt1w: scene arm %d, %ldx%ld, %ld spp, depth %ld\n", arm, width, height, spp, depth);
     if (rt1w_render_rows(ctx, &p, 0, RT1W_ROWS_U8, img.data(), on_rows, &sink, &st) < 0) return fail("render");
-    std::fprintf(stderr, "\nDone\nrt1w: %.1f ms kernels, %.1f Mpaths/s, %.2f segments/path, kernel variant V%u\n", st.kernel_ms,
-                 (double)st.paths / st.kernel_ms / 1e3, (double)st.segments / (double)st.paths, st.variant);
+    std::fprintf(stderr, "\nDone\nrt1w: %.1f ms kernels, %.1f Mpaths/s, %.2f segments/path, kernel variant V%u%s\n", st.kernel_ms,
+                 (double)st.paths / st.kernel_ms / 1e3, (double)st.segments / (double)st.paths, st.variant, (st.sorted & 4u) ? " (scene-specialised)" : "");
     if (o != stdout) std::fclose(o);
     rt1w_context_destroy(ctx);
     rt1w_scene_destroy(scene);
