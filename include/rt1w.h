@@ -142,6 +142,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
 #define RT1W_GENERIC 8u   /* do not use a scene-specialised kernel even if the context has one (rt1w_context_specialise) */
+#define RT1W_WAVEFRONT 16u /* experiment, big scenes (stack-walk variants) only: path state queued in HBM, trace and shade as separate kernels per bounce; bit-identical, measured 0.45-0.7x the default */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering) */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 

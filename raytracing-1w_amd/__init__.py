@@ -36,6 +36,7 @@ OUT_SUM = 1
 UNSORTED = 2
 LDS_NODES = 4
 GENERIC = 8  # do not use a scene-specialised kernel for this render
+WAVEFRONT = 16  # big scenes: path state queued in HBM, trace / shade kernels per bounce
 SPECIALISE_CACHED_ONLY = 1
 
 
@@ -316,9 +317,9 @@ class Context:
     __del__ = close
 
     @staticmethod
-    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False):
+    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        flags = (OUT_SUM if out_sum else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        flags = (OUT_SUM if out_sum else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (((variant + 1) << 8) if variant is not None else 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags)
 
     def specialise(self, cached_only=False):
@@ -337,9 +338,9 @@ class Context:
         return rc == 0 and bool(info.active)
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-               variant=None, unsorted=False, lds_nodes=False, generic=False):
+               variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict)."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront)
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
         st = Stats()
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))

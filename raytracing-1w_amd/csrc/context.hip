@@ -29,6 +29,7 @@
 
 #include "rt1w.h"
 #include "rt_kernel_sorted.h"
+#include "rt_wavefront.h"
 #include "scene.h"
 #include "jit.h"
 
@@ -243,6 +244,11 @@ struct rt1w_context {
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
+    /* wavefront form (rt_wavefront.h): path records, two queues, per-sample radiance of one chunk, counters */
+    void* wf_paths = nullptr; uint32_t* wf_queue[2] = {nullptr, nullptr}; double* wf_rad = nullptr;
+    unsigned long long* wf_counters = nullptr; unsigned long long* wf_hcounters = nullptr;
+    size_t wf_paths_cap = 0, wf_rad_cap = 0;
+    int wf_grid[RT_N_VARIANTS] = {0, 0, 0, 0};
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
     hipModule_t jit_mod = nullptr;
@@ -415,6 +421,99 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
     return RT1W_OK;
 }
 
+typedef void (*wf_trace_t)(RtSceneView, WfPath*, const uint32_t*, unsigned long long, unsigned long long*, uint32_t);
+typedef void (*wf_shade_t)(RtSceneView, WfPath*, const uint32_t*, unsigned long long, uint32_t*, unsigned long long*, double*, unsigned long long);
+static wf_trace_t const g_wf_trace[RT_N_VARIANTS] = {nullptr, nullptr, wf_trace<RtCfgV2>, wf_trace<RtCfgV3>};
+static wf_shade_t const g_wf_shade[RT_N_VARIANTS] = {nullptr, nullptr, wf_shade<RtCfgV2>, wf_shade<RtCfgV3>};
+#define RT_WF_PASS_PATHS (16ull << 20) /* paths in flight per pass: 16 Mi x 200 B = 3.4 GB of path records */
+
+/* the wavefront form of one render: per chunk of samples, passes of <= RT_WF_PASS_PATHS paths, per pass
+ * generate -> (trace -> shade)* until the queue is empty; then the chunk's samples are summed in order */
+int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunch& L, double* d_out, rt1w_stats* stats) {
+    RtLane& l = c->lane[0];
+    const RtFrame& f = L.f;
+    const unsigned long long npix = L.npix;
+    const int v = L.variant;
+    if (!g_wf_trace[v]) { rt1w::set_error("the wavefront form exists for the stack-walk variants only"); return RT1W_ERR_INVALID; }
+    if (npix > RT_WF_PASS_PATHS) { rt1w::set_error("wavefront form: tile larger than one pass (render it in strips)"); return RT1W_ERR_UNSUPPORTED; }
+    const uint32_t s_pass_max = (uint32_t)(RT_WF_PASS_PATHS / npix);
+    const size_t paths_cap = (size_t)npix * (f.chunk < s_pass_max ? f.chunk : s_pass_max);
+    const size_t rad_cap = (size_t)npix * f.chunk;
+    if (paths_cap > c->wf_paths_cap) {
+        if (c->wf_paths) (void)hipFree(c->wf_paths);
+        for (int k = 0; k < 2; ++k) { if (c->wf_queue[k]) (void)hipFree(c->wf_queue[k]); c->wf_queue[k] = nullptr; }
+        c->wf_paths = nullptr; c->wf_paths_cap = 0;
+        if (!hip_ok(hipMalloc(&c->wf_paths, paths_cap * sizeof(WfPath)), "hipMalloc(path records)") ||
+            !hip_ok(hipMalloc((void**)&c->wf_queue[0], paths_cap * sizeof(uint32_t)), "hipMalloc(queue)") ||
+            !hip_ok(hipMalloc((void**)&c->wf_queue[1], paths_cap * sizeof(uint32_t)), "hipMalloc(queue)")) return RT1W_ERR_NOMEM;
+        c->wf_paths_cap = paths_cap;
+    }
+    if (rad_cap > c->wf_rad_cap) {
+        if (c->wf_rad) (void)hipFree(c->wf_rad);
+        c->wf_rad = nullptr; c->wf_rad_cap = 0;
+        if (!hip_ok(hipMalloc((void**)&c->wf_rad, rad_cap * 3 * sizeof(double)), "hipMalloc(sample radiance)")) return RT1W_ERR_NOMEM;
+        c->wf_rad_cap = rad_cap;
+    }
+    if (!c->wf_counters) {
+        if (!hip_ok(hipMalloc((void**)&c->wf_counters, 4 * sizeof(unsigned long long)), "hipMalloc(counters)") ||
+            !hip_ok(hipHostMalloc((void**)&c->wf_hcounters, 4 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(counters)")) return RT1W_ERR_NOMEM;
+    }
+    if (!c->wf_grid[v]) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_wf_trace[v], RT_BLOCK, 0), "occupancy query") ||
+            !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
+        c->wf_grid[v] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+    }
+    unsigned long long segments = 0;
+    const uint32_t refill = RT_WF_REFILL;
+    (void)hipEventRecord(l.ev0, l.stream);
+    for (uint32_t ch = 0; ch < f.n_chunks; ++ch) {
+        const uint32_t s_begin = ch * f.chunk;
+        const uint32_t s_cnt = s_begin + f.chunk < f.spp ? f.chunk : f.spp - s_begin;
+        for (uint32_t s0 = 0; s0 < s_cnt; s0 += s_pass_max) {
+            const uint32_t s_n = s_cnt - s0 < s_pass_max ? s_cnt - s0 : s_pass_max;
+            unsigned long long n = npix * s_n;
+            hipLaunchKernelGGL(wf_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, l.stream, c->view, f, (WfPath*)c->wf_paths,
+                               c->wf_queue[0], s_begin + s0, s_n);
+            int q = 0;
+            while (n > 0) {
+                /* [0] next queue index, [1] segments of this launch, [2] length of the next queue */
+                if (!hip_ok(hipMemsetAsync(c->wf_counters, 0, 3 * sizeof(unsigned long long), l.stream), "counter reset")) return RT1W_ERR_DEVICE;
+                hipLaunchKernelGGL(g_wf_trace[v], dim3(c->wf_grid[v]), dim3(RT_BLOCK), 0, l.stream, c->view, (WfPath*)c->wf_paths,
+                                   (const uint32_t*)c->wf_queue[q], n, c->wf_counters, refill);
+                hipLaunchKernelGGL(g_wf_shade[v], dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, l.stream, c->view,
+                                   (WfPath*)c->wf_paths, (const uint32_t*)c->wf_queue[q], n, c->wf_queue[q ^ 1], c->wf_counters,
+                                   c->wf_rad, (unsigned long long)s0 * npix);
+                if (!hip_ok(hipGetLastError(), "kernel launch") ||
+                    !hip_ok(hipMemcpyAsync(c->wf_hcounters, c->wf_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream), "counter copy") ||
+                    !hip_ok(hipStreamSynchronize(l.stream), "wavefront bounce")) return RT1W_ERR_DEVICE;
+                segments += c->wf_hcounters[1];
+                n = c->wf_hcounters[2];
+                q ^= 1;
+            }
+        }
+        hipLaunchKernelGGL(wf_chunk_sum, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, l.stream, (const double*)c->wf_rad,
+                           l.d_partial + (size_t)ch * npix * 3, npix, s_cnt);
+    }
+    {
+        unsigned int rb = 256;
+        unsigned int rg = (unsigned int)((npix + rb - 1) / rb);
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, npix, f.n_chunks, f.spp,
+                           (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
+    }
+    (void)hipEventRecord(l.ev1, l.stream);
+    if (!hip_ok(hipGetLastError(), "kernel launch") || !hip_ok(hipStreamSynchronize(l.stream), "wavefront render")) return RT1W_ERR_DEVICE;
+    if (stats) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, l.ev0, l.ev1);
+        stats->paths = npix * f.spp; stats->segments = segments; stats->kernel_ms = ms;
+        stats->chunk = f.chunk; stats->n_chunks = f.n_chunks; stats->grid = (uint32_t)c->wf_grid[v]; stats->block = RT_BLOCK;
+        stats->variant = (uint32_t)v; stats->sorted = 8u; /* bit 3: wavefront form */
+    }
+    return RT1W_OK;
+}
+
 int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, rt1w_stats* stats) {
     /* a render this long repays the 1-8 s of the compiler: 2^35 paths where the gain is ~1.3x (scenes the generic sweep
      * handles), 2^32 where it is 1.5-2.3x (scenes the generic code hands to the stack walk).  RT1W_NO_JIT: never compile
@@ -430,6 +529,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
     if (rc < 0) return rc;
     RtLane& l = c->lane[0];
     if ((rc = lane_reserve_partial(l, L)) < 0) return rc;
+    if ((p->flags & RT1W_WAVEFRONT) && !L.jit && !L.sorted) return render_wavefront(c, p, L, d_out, stats);
     if ((rc = render_launch(c, l, p, L, d_out)) < 0) return rc;
     return render_finish(l, L, stats);
 }
@@ -534,7 +634,9 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
 void rt1w_context_destroy(rt1w_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images, c->d_out};
+    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images, c->d_out,
+                    c->wf_paths, c->wf_queue[0], c->wf_queue[1], c->wf_rad, c->wf_counters};
+    if (c->wf_hcounters) (void)hipHostFree(c->wf_hcounters);
     for (void* b : bufs) if (b) (void)hipFree(b);
     lane_destroy(c->lane[0]);
     lane_destroy(c->lane[1]);

@@ -481,3 +481,18 @@ def test_scene_specialised_kernels_are_bit_identical(rt, gpu_ctx_factory, tmp_pa
     with pytest.raises(rt.Rt1wError) as e:
         big.specialise()
     assert e.value.code == rt.ERR_UNSUPPORTED and not big.specialised()
+
+
+def test_wavefront_form_is_bit_identical(rt, gpu_ctx_factory):
+    """RT1W_WAVEFRONT (rt_wavefront.h): the big scenes with the path state queued in HBM and one trace + one shade kernel per
+    bounce (lanes refill from the queue as their walks end).  Same per-path function, samples still summed in order per chunk:
+    bits and segment counts equal the persistent kernel's -- several chunks, several passes per chunk, a tile, raw sums."""
+    for arm, aspect in ((0, 1.5), (7, None)):
+        ctx = gpu_ctx_factory(rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect))
+        for (W, H, spp, kw) in ((96, 64, 20, dict(chunk=8)), (64, 48, 5, dict(tile=(5, 7, 40, 30), sample_offset=3, out_sum=True))):
+            a, sa = ctx.render(W, H, spp, **kw)
+            b, sb = ctx.render(W, H, spp, wavefront=True, **kw)
+            assert sb["sorted"] == 8 and sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (arm, W, H)
+    small = gpu_ctx_factory(rt.Scene.reference(5, build_seed=1))
+    c, sc_ = small.render(32, 32, 4, wavefront=True)      # sweep scenes keep their own kernels: the flag is ignored
+    assert sc_["sorted"] != 8
