@@ -1,5 +1,6 @@
 """Generates the committed golden fixtures.  Run in the build container only:
     python tests/golden/make_golden.py
+(0) pixel-level fixture of the reference's own render rest_of_your_life.png (hash, row checksums, a crop);
 (1) block means of the reference's own artefacts rest_of_your_life.png (Cornell, master) and next_week.png
     (final_scene, an earlier revision) read from /root/reference -- the only outputs of the reference's own runs
     that match a scene arm of master (one_weekend.png is the book-1 scene: gradient sky, no checker, no motion blur);
@@ -38,6 +39,22 @@ def png_blocks_final():
     return {"source": "next_week.png (hatoo/raytracing-1w, README.md:15; rendered by an earlier revision, see make_golden.py)",
             "shape": [800, 800], "block": 100, "linear_block_means_top_down": b.tolist(), "selected_blocks": sel}
 
+def png_pixels():
+    """Pixel-level pin: rest_of_your_life.png IS what `cargo run` of master prints (Cornell arm, 600x600, 100 spp,
+    main.rs:868-870), converted losslessly from the P3 text.  The per-pixel stream is deterministic (main.rs:964) and the
+    scene has no build-time randomness that reaches a pixel, so the literal oracle in reference-stream mode
+    (oracle/refstream.h: ChaCha12 + rand 0.8.4 shapes + libm) must reproduce it pixel for pixel.  Committed: sha256 of
+    the RGB bytes (rows top-down), crc32 of every row, and a 128x128 crop (sphere, box edge, floor, wall)."""
+    import zlib
+    from PIL import Image
+    im = np.ascontiguousarray(np.asarray(Image.open('/root/reference/rest_of_your_life.png').convert('RGB'), dtype=np.uint8))
+    assert im.shape == (600, 600, 3)
+    x0, y0 = 150, 330   # top-down coordinates of the crop
+    np.save(os.path.join(HERE, 'cornell_png_crop.npy'), im[y0:y0 + 128, x0:x0 + 128])
+    return {"source": "rest_of_your_life.png (hatoo/raytracing-1w master, README.md:19)", "shape": [600, 600, 3], "spp": 100,
+            "depth": 50, "arm": 5, "sha256_rgb_top_down": hashlib.sha256(im.tobytes()).hexdigest(),
+            "row_crc32_top_down": [zlib.crc32(im[r].tobytes()) for r in range(600)], "crop_top_down": [x0, y0, 128, 128]}
+
 CASES = {  # name: (arm, W, H, spp, depth)
     "c1_cornell_200x200x64": (5, 200, 200, 64, 50),
     "random_scene_96x64x8": (0, 96, 64, 8, 50),
@@ -55,6 +72,8 @@ def main():
         json.dump(png_blocks(), f, indent=1)
     with open(os.path.join(HERE, 'final_scene_png_blocks.json'), 'w') as f:
         json.dump(png_blocks_final(), f, indent=1)
+    with open(os.path.join(HERE, 'cornell_png_pixels.json'), 'w') as f:
+        json.dump(png_pixels(), f, indent=1)
     meta = {}
     arrays = {}
     for name, (arm, W, H, spp, depth) in CASES.items():

@@ -13,7 +13,7 @@ _P = C.c_void_p
 
 
 def _build():
-    need = [os.path.join(ORACLE_DIR, n) for n in ("liborc_rt1w.so", "liborc_flat.so")]
+    need = [os.path.join(ORACLE_DIR, n) for n in ("liborc_rt1w.so", "liborc_flat.so", "liborc_ref.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
@@ -21,6 +21,22 @@ def _build():
 _build()
 A = C.CDLL(os.path.join(ORACLE_DIR, "liborc_rt1w.so"))
 B = C.CDLL(os.path.join(ORACLE_DIR, "liborc_flat.so"))
+
+# the same restatement with the reference's own generator + libm (oracle/refstream.h)
+REF = C.CDLL(os.path.join(ORACLE_DIR, "liborc_ref.so"))
+for _L in (A, REF):
+    _L.orc_scene_build.restype = _P
+    _L.orc_scene_build.argtypes = [C.c_int, C.c_uint64, C.c_double, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
+    _L.orc_scene_free.argtypes = [_P]
+    _L.orc_render.restype = C.c_int
+    _L.orc_render.argtypes = [_P] + [C.c_uint32] * 10 + [C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]
+    _L.orc_render_checkpoints.restype = C.c_int
+    _L.orc_render_checkpoints.argtypes = [_P] + [C.c_uint32] * 10 + [C.c_int, C.c_int, _P, C.c_uint32, _P, C.POINTER(C.c_uint64)]
+    _L.orc_quantize.argtypes = [_P, C.c_uint64, _P]
+    _L.orc_is_refstream.restype = C.c_int
+REF.orc_ref_chacha_block.argtypes = [_P, C.c_uint64, C.c_int, _P]
+REF.orc_ref_stdrng_construction.argtypes = [_P, _P]
+REF.orc_ref_words.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, _P]
 
 A.orc_scene_build.restype = _P
 A.orc_scene_build.argtypes = [C.c_int, C.c_uint64, C.c_double, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
@@ -50,9 +66,13 @@ def default_aspect(arm):
 
 
 class OracleScene:
-    """Literal recursive oracle (oracle/oracle.cpp)."""
+    """Literal recursive oracle (oracle/oracle.cpp).  refstream=True: the build with the reference's own ChaCha12
+    per-pixel stream and libm (liborc_ref.so) instead of the Philox streams of the numerical contract."""
 
-    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None):
+    lib = A  # class default (subclasses that wrap a ready handle); instances made with refstream=True use REF
+
+    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False):
+        self.lib = REF if refstream else A
         if aspect_ratio is None:
             aspect_ratio = default_aspect(arm)
         self.earth = None
@@ -63,14 +83,14 @@ class OracleScene:
             eh, ew = self.earth.shape[:2]
             ptr = self.earth.ctypes.data_as(_P)
         d = (C.c_uint32 * 3)()
-        self._h = A.orc_scene_build(arm, build_seed, aspect_ratio, ptr, ew, eh, C.byref(d))
+        self._h = self.lib.orc_scene_build(arm, build_seed, aspect_ratio, ptr, ew, eh, C.byref(d))
         if not self._h:
             raise RuntimeError("oracle scene build failed")
         self.defaults = (d[0], d[1], d[2])
 
     def __del__(self):
         if getattr(self, "_h", None):
-            A.orc_scene_free(self._h)
+            self.lib.orc_scene_free(self._h)
             self._h = None
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, out_sum=False, threads=None):
@@ -78,10 +98,29 @@ class OracleScene:
         out = np.empty((th, tw, 3), dtype=np.float64)
         seg = C.c_uint64()
         threads = threads or min(16, os.cpu_count() or 1)
-        rc = A.orc_render(self._h, width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed,
-                          1 if out_sum else 0, threads, out.ctypes.data_as(_P), C.byref(seg))
+        rc = self.lib.orc_render(self._h, width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed,
+                                 1 if out_sum else 0, threads, out.ctypes.data_as(_P), C.byref(seg))
         assert rc == 0
         return out, {"segments": seg.value, "paths": tw * th * spp}
+
+    def render_checkpoints(self, width, height, checkpoints, max_depth=50, tile=None, threads=None):
+        """One pass over max(checkpoints) samples; returns the means after each checkpoint: [n_cp][th][tw][3]."""
+        x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
+        cp = (C.c_uint32 * len(checkpoints))(*checkpoints)
+        out = np.empty((len(checkpoints), th, tw, 3), dtype=np.float64)
+        seg = C.c_uint64()
+        threads = threads or min(16, os.cpu_count() or 1)
+        rc = self.lib.orc_render_checkpoints(self._h, width, height, x0, y0, tw, th, checkpoints[-1], 0, max_depth, 0, 0,
+                                             threads, cp, len(checkpoints), out.ctypes.data_as(_P), C.byref(seg))
+        assert rc == 0
+        return out, {"segments": seg.value, "paths": tw * th * checkpoints[-1]}
+
+    def quantize(self, means):
+        """The oracle's own quantiser (color.rs:56-65), not the product's."""
+        m = np.ascontiguousarray(means, dtype=np.float64)
+        q = np.empty(m.shape, dtype=np.uint8)
+        self.lib.orc_quantize(m.ctypes.data_as(_P), m.size, q.ctypes.data_as(_P))
+        return q
 
 
 class Frame(C.Structure):
