@@ -1,49 +1,75 @@
 #!/usr/bin/env python3
 """bench.py -- Mpaths/s of the per-pixel sample loop on MI355X (BASELINE.json metric).
 
-A "step" = one render of the workload: BASELINE config C3, the reference's Cornell box
-(src/main.rs:395-512, lights :873-887, camera :888-892) at 600x600, 1000 spp, depth 50,
-f64, scene procedural (no external data), scene + camera resident in HBM before timing,
-framebuffer left in HBM (device-resident rate; the host-copy-inclusive rate is reported
-as `value_incl_d2h`, never as `value`).
+A "step" = one render of the workload INCLUDING the device->host gather (t_render covers kernel(s) +
+device->host gather; scene build/upload and PPM text excluded).  The scene and camera are resident in HBM before timing.
 
-N GPUs (one process per GPU, launched by torch.distributed.run): weak scaling by sample range --
-rank r renders samples [r*1000, (r+1)*1000) of every pixel; no data-path collective (the
-ranks only share a barrier and a max-reduce of the elapsed time).
+  N = 1  BASELINE config C3: the reference's Cornell box (src/main.rs:395-512, lights :873-887, camera :888-892),
+         600x600, 1000 spp, depth 50, f64, into a pinned host frame (rt1w_render, RT1W_OUT_FRAME).
+  N > 1  the SAME job shape, image-tiled over the GPUs of one node as the north star says: 16-row strips dealt round-robin
+         (sharding.interleaved_tile; one launch per GPU renders all of its strips), every rank's device->host copy writes
+         its strips straight into ONE shared pinned host frame (sharding.SharedFrame) -- the host gather, inside the
+         timed region.  No data-path collective; ranks share a barrier and a max-reduce of the elapsed time (gloo).
+         Weak scaling (task rule: independent units sharded across ranks): the frame grows with N at constant 1000 spp
+         and constant camera -- side = 8*round(600*sqrt(N)/8): 600, 848, 1200, 1696 -- so every GPU keeps C3's 3.6e8
+         paths per step and the per-pixel cost distribution of the Cornell view.  --strong keeps C3's 600x600 for all N.
+         --workload c5 is BASELINE config C5 (3840x2160, 16:9) at --spp (default 1000; 10 000 takes 22 s per step per GPU).
+
+`value` = whole-job paths / s over the timed steps, copy included.  The device-resident rate (framebuffer left in HBM)
+is reported as `value_device_resident`, never as `value`.
 """
 import argparse
+import importlib
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-W, H, SPP, DEPTH = 600, 600, 1000, 50
+C3_W, C3_H, SPP, DEPTH = 600, 600, 1000, 50
 RECORD_BYTES = 128          # f64 SoA ray-state record
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(cores):
-    """Literal C++ restatement of the reference (oracle/oracle.cpp, kind 'port' -- the Rust crate
-    cannot be built here), same scene/camera/size, bounded spp (Mpaths/s does not depend on spp)."""
+def cpu_baseline(width, height):
+    """Literal C++ restatement of the reference (oracle/oracle.cpp, kind 'port': the Rust crate cannot be built here --
+    no rustc/cargo), same scene/camera/size, all host cores (rayon's default, src/main.rs:957-963) AND one thread,
+    on a bounded spp (Mpaths/s does not depend on spp).  The only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    sc = orc.OracleScene(5, build_seed=1)
-    spp = 4
-    t0 = time.time()
-    _, st = sc.render(W, H, spp, max_depth=DEPTH, threads=cores)
-    dt = time.time() - t0
-    # scale the sample to ~12 s of CPU work
-    spp2 = max(4, min(512, int(spp * 12.0 / max(dt, 1e-3))))
-    t0 = time.time()
-    _, st = sc.render(W, H, spp2, max_depth=DEPTH, threads=cores)
-    dt = time.time() - t0
-    return {"value": round(st["paths"] / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
-            "sample": f"cornell_box {W}x{H}, {spp2} spp, depth {DEPTH} ({st['paths']} paths, {dt:.1f} s, "
-                      f"std::thread pool of {cores})"}
+    sc = orc.OracleScene(5, build_seed=1, aspect_ratio=width / height)
+    cores = os.cpu_count() or 1
+
+    def run(threads, budget_s):
+        spp = 2
+        t0 = time.time()
+        sc.render(width, height, spp, max_depth=DEPTH, threads=threads)
+        dt = time.time() - t0
+        spp2 = max(2, min(512, int(spp * budget_s / max(dt, 1e-3))))
+        t0 = time.time()
+        _, st = sc.render(width, height, spp2, max_depth=DEPTH, threads=threads)
+        dt = time.time() - t0
+        return st["paths"] / dt / 1e6, spp2, st["paths"], dt
+
+    v_all, spp_all, paths_all, dt_all = run(cores, 12.0)
+    v_one, spp_one, paths_one, dt_one = run(1, 8.0)
+    return {"value": round(v_all, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            "sample": f"cornell_box {width}x{height}, {spp_all} spp, depth {DEPTH} ({paths_all} paths in {dt_all:.1f} s on a "
+                      f"std::thread pool of {cores} = os.cpu_count(); oracle built -O3)",
+            "single_thread": {"value": round(v_one, 4), "cores": 1,
+                              "sample": f"{spp_one} spp ({paths_one} paths in {dt_one:.1f} s)"}}
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
 
 
 def main():
@@ -53,14 +79,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="ablation: the generic kernel instead of the scene-specialised one")
-    ap.add_argument("--spp", type=int, default=SPP, help="debug only; the contract workload is 1000")
+    ap.add_argument("--spp", type=int, default=SPP, help="the contract workload is 1000")
+    ap.add_argument("--workload", choices=("c3", "c5"), default="c3")
+    ap.add_argument("--strong", action="store_true", help="N > 1: keep the N = 1 frame (strong scaling of one job)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only (1-GPU box): every rank uses this device instead of LOCAL_RANK")
+    ap.add_argument("--check-frame", action="store_true",
+                    help="after timing, rank 0 renders the whole frame alone and requires the gathered frame to be bit-identical")
     a = ap.parse_args()
 
+    import numpy as np
     import torch
-    import orc
-    rt = orc.rt()
+    rt = importlib.import_module("raytracing-1w_amd")          # the product; oracle/ is only touched by cpu_baseline()
+    sharding = importlib.import_module("raytracing-1w_amd.sharding")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,7 +107,16 @@ def main():
         local_rank = a.all_ranks_on_device
     assert torch.cuda.is_available() and rt.device_count() > local_rank, "bench.py needs the GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    scene = rt.Scene.reference(5, build_seed=1)
+
+    if a.workload == "c5":
+        W, H, aspect, name = 3840, 2160, 16.0 / 9.0, "C5 cornel_box 16:9"
+        if world > 1 and not a.strong:
+            a.strong = True                                              # C5 is one fixed frame
+    else:
+        side = C3_W if (a.strong or world == 1) else 8 * round(C3_W * math.sqrt(world) / 8)
+        W, H, aspect, name = side, side, 1.0, "C3 cornel_box"
+    spp = a.spp
+    scene = rt.Scene.reference(5, build_seed=1, aspect_ratio=aspect)
     ctx = rt.Context(scene, local_rank)
     # kernel specialised for this scene's topology: from the kernel cache the build fills (raytracing-1w_amd/kernels), or compiled
     # here with hiprtc (3-5 s, outside the timed region like the rest of the set-up); --generic keeps the generic kernel
@@ -86,9 +126,29 @@ def main():
             spec = ctx.specialise()
         except rt.Rt1wError as e:
             spec = {"active": False, "error": str(e)}
-    spp = a.spp
-    out = torch.empty((H, W, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
-    kw = dict(max_depth=DEPTH, sample_offset=rank * spp, out_sum=(world > 1), generic=a.generic)
+
+    # the whole-image host frame every rank's copy lands in
+    shm_name = f"rt1w_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}"
+    if world > 1:
+        if rank == 0:
+            frame = sharding.SharedFrame(shm_name, W, H, True, rt)
+        dist.barrier()
+        if rank != 0:
+            frame = sharding.SharedFrame(shm_name, W, H, False, rt)
+        host = frame.array
+    else:
+        frame = None
+        host = rt.pinned_empty((H, W, 3))
+    y0, rows, srows, period = sharding.interleaved_tile(H, world, rank)
+    chunk = rt.default_chunk(W, H, spp)                                  # the whole frame's chunking: same sums as one GPU
+    kw = dict(max_depth=DEPTH, generic=a.generic, chunk=chunk)
+    tile = (0, y0, W, rows)
+
+    def step():
+        if rows == 0:
+            return None
+        _, st = ctx.render(W, H, spp, tile=tile, strips=(srows, period), frame=host, **kw)
+        return st
 
     def barrier():
         if dist is not None:
@@ -96,72 +156,106 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        ctx.render_device(out.data_ptr(), W, H, spp, **kw)
+        step()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = []
     segs = 0
+    st = None
     for _ in range(a.steps):
-        st = ctx.render_device(out.data_ptr(), W, H, spp, **kw)
-        kernel_ms.append(st["kernel_ms"])
-        segs = st["segments"]
+        st = step()
+        if st is not None:
+            kernel_ms.append(st["kernel_ms"])
+            segs = st["segments"]
     barrier()
     elapsed = time.perf_counter() - t0
+    seg_total = segs
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        t = torch.tensor([elapsed, float(segs)], dtype=torch.float64)
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tm[0])
+        seg_total = int(t[1])
 
-    paths_per_step = W * H * spp * world
+    paths_per_step = W * H * spp
     value = paths_per_step * a.steps / elapsed / 1e6
 
+    frame_check = None
+    if a.check_frame:
+        barrier()
+        if rank == 0:
+            solo, _ = ctx.render(W, H, spp, **kw)
+            frame_check = bool(np.array_equal(solo, host, equal_nan=True))
+            assert frame_check, "gathered frame differs from the single-GPU frame"
+
+    # device-resident rate of this rank's share (framebuffer left in HBM), outside the timed region
+    dev_ms = None
+    if rows:
+        out = torch.empty((rows, W, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(1, min(a.steps, 3))):
+            ctx.render_device(out.data_ptr(), W, H, spp, tile=tile, strips=(srows, period), **kw)
+        torch.cuda.synchronize()
+        dev_ms = (time.perf_counter() - t1) / max(1, min(a.steps, 3)) * 1e3
+
     if rank == 0:
-        # roofline of the dominant kernel (rt_render_kernel): algorithmic bytes per launch =
-        # 2 * 128 B per traced segment (ray-state record read + written once per segment) + 24 B per pixel
+        # roofline of the dominant kernel: algorithmic bytes per launch = 2 * 128 B per traced segment (ray-state record
+        # read + written once per segment) + 24 B per pixel; HIP events on the kernel's own stream
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        algo_bytes = 2 * RECORD_BYTES * segs + 24 * W * H
+        my_pixels = rows * W
+        algo_bytes = 2 * RECORD_BYTES * segs + 24 * my_pixels
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = None
+        flags = st.get("sorted", 0)
+        kernel = "rt_jit_sorted" if (flags & 4) else ("rt_render_kernel_sorted<V%d>" % st["variant"] if (flags & 1) else "rt_render_kernel<V%d>" % st["variant"])
+        # HBM traffic from the PMC counters is a STORED measurement (separate rocprofv3 --pmc passes, profiles/): it is only
+        # attached when it was taken on this very kernel (same specialisation key), and carries the commit it was taken at
+        traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
                 prof = json.load(open(tp))
-                traffic = prof.get("hbm_bytes_per_launch")   # rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command (profiles/)
-                pmc = prof.get("pmc")
+                same = bool(spec) and prof.get("specialise_key") == spec.get("key") and world == 1 and a.workload == "c3" and spp == SPP
+                traffic_src = {"file": "profiles/hbm_traffic.json", "measured_at_commit": prof.get("commit"),
+                               "kernel_key": prof.get("specialise_key"), "matches_this_run": same, "pmc": prof.get("pmc") if same else None}
+                if same:
+                    traffic = prof.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pass
         line = {
             "metric": "Mpaths/s", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "scaling": "strong" if (a.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (procedural Cornell box of the reference, build_seed 1; no external data)",
-            "config": {"workload": f"C3 cornel_box (scene arm 5) {W}x{H}, {spp} spp per GPU, depth {DEPTH}, "
-                                   f"mixture-PDF light sampling; N GPUs = sample ranges [r*{spp},(r+1)*{spp})",
-                       "width": W, "height": H, "spp_per_gpu": spp, "max_depth": DEPTH,
-                       "paths_per_step": paths_per_step, "segments_per_path": round(segs / (W * H * spp), 4),
+            "config": {"workload": f"{name} (scene arm 5) {W}x{H}, {spp} spp, depth {DEPTH}, mixture-PDF light sampling; "
+                                   f"timed region = kernels + device->host gather into one pinned host frame",
+                       "width": W, "height": H, "spp": spp, "max_depth": DEPTH,
+                       "paths_per_step": paths_per_step, "segments_per_path": round(seg_total / paths_per_step, 4),
                        "chunk": st["chunk"], "n_chunks": st["n_chunks"], "grid": st["grid"], "block": st["block"],
-                       "kernel_variant": st["variant"], "workgroup_path_sort": bool(st.get("sorted", 0) & 1),
-                       "scene_specialised_kernel": bool(st.get("sorted", 0) & 4), "specialise": spec,
-                       "parallelism": f"sample-range x{world}, host gather, no collective"},
+                       "kernel_variant": st["variant"], "workgroup_path_sort": bool(flags & 1),
+                       "scene_specialised_kernel": bool(flags & 4), "specialise": spec,
+                       "parallelism": (f"image-tiled x{world}: 16-row strips round-robin, one launch per GPU, every GPU's D2H writes its "
+                                       f"strips into one shared pinned host frame (host gather, no collective)") if world > 1
+                                      else "1 GPU, D2H into a pinned host frame",
+                       "commit": git_head()},
+            "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "rt_jit_sorted" if (st.get("sorted", 0) & 4) else ("rt_render_kernel_sorted<V%d>" % st["variant"] if (st.get("sorted", 0) & 1) else "rt_render_kernel<V%d>" % st["variant"]),
-                         "kernel_ms": round(avg_ms, 3),
-                         "algorithmic_bytes_per_launch": algo_bytes, "pmc": pmc,
-                         "note": "compute-bound f64 kernel: ray state stays in VGPRs, so real HBM traffic is far "
-                                 "below the algorithmic record traffic of SURVEY 8(d)"},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "kernel_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
+                         "true_limiter": "f64 VALU issue + lane divergence: the ray state stays in VGPRs, so measured HBM "
+                                         "traffic is ~600x below the algorithmic record traffic the graded roofline counts"},
         }
-        if world == 1:
-            # host-copy-inclusive rate (rt1w_render into host memory), reported separately
-            t1 = time.perf_counter()
-            _, st2 = ctx.render(W, H, spp, max_depth=DEPTH)
-            line["value_incl_d2h"] = round(W * H * spp / (time.perf_counter() - t1) / 1e6, 2)
-            if not a.no_cpu_baseline:
-                cores = min(16, os.cpu_count() or 1)
-                line["cpu_baseline"] = cpu_baseline(cores)
+        if frame_check is not None:
+            line["gathered_frame_equals_single_gpu_frame"] = frame_check
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(W, H)
         print(json.dumps(line), flush=True)
     ctx.close()
+    if frame is not None:
+        if dist is not None:
+            dist.barrier()
+        frame.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -143,6 +143,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
 #define RT1W_GENERIC 8u   /* do not use a scene-specialised kernel even if the context has one (rt1w_context_specialise) */
 #define RT1W_WAVEFRONT 16u /* experiment, big scenes (stack-walk variants) only: path state queued in HBM, trace and shade as separate kernels per bounce; bit-identical, measured 0.45-0.7x the default */
+#define RT1W_OUT_FRAME 32u /* rt1w_render only: `out_rgb` is the WHOLE image [height][width][3] (row 0 = j = 0) and the call writes just its tile's pixels at their image positions -- several contexts / processes fill one (shared, pinned) host frame: the host gather of the image-tiled multi-GPU job */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering) */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
@@ -155,7 +156,16 @@ typedef struct rt1w_render_params {
     uint32_t global_seed;
     uint32_t chunk;                 /* samples per work item, 0 = library default (rt1w_default_chunk) */
     uint32_t flags;                 /* RT1W_OUT_* */
+    /* Row-interleaved tile, for tiling ONE image over several GPUs with balanced load (the reference hands rows to rayon
+     * workers, src/main.rs:957-963; Cornell rows differ in cost by region): the tile's rows are strips of `strip_rows`
+     * image rows taken every `strip_period` rows, i.e. tile row r is image row y0 + (r / strip_rows) * strip_period +
+     * r % strip_rows.  Rank k of n passes y0 = k * strip_rows, strip_period = n * strip_rows, tile_h = the rows it owns.
+     * Both 0: an ordinary contiguous tile.  One launch renders all of the rank's strips. */
+    uint32_t strip_rows, strip_period;
+    uint32_t precision;             /* RT1W_PRECISION_*: 0 = f64, the reference's `type Float = f64` (src/main.rs:1) */
+    uint32_t reserved;              /* must be 0 */
 } rt1w_render_params;
+#define RT1W_PRECISION_F64 0u
 
 typedef struct rt1w_stats {
     uint64_t paths;        /* pixels * spp */
@@ -203,6 +213,14 @@ typedef int (*rt1w_progress_fn)(void* user, uint32_t rows_done, uint32_t rows_to
 int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t strip_rows, int format, void* out,
                      rt1w_progress_fn progress, void* user, rt1w_stats* stats);
 
+/* Page-locked host memory for output frames (hipHostMalloc / hipHostRegister): device->host copies into it run at full
+ * PCIe rate and asynchronously.  rt1w_host_register pins memory the caller already owns, e.g. a POSIX shared-memory
+ * mapping that several single-GPU processes fill with RT1W_OUT_FRAME. */
+int rt1w_host_alloc(uint64_t bytes, void** out);
+int rt1w_host_free(void* p);
+int rt1w_host_register(void* p, uint64_t bytes);
+int rt1w_host_unregister(void* p);
+
 /* ---- scene-specialised kernels ----
  * Small scenes are traversed by a stackless pre-order sweep.  When the node kinds and subtree ends are compile-time
  * constants that sweep unrolls into straight-line code along the scene's own tree (same arithmetic, bit-identical
@@ -237,6 +255,10 @@ int rt1w_quantize(const double* means, uint64_t n_values, uint8_t* out);
  * (rows are emitted top-down, j = height-1 first).  Returns bytes written
  * (excluding NUL) or needed size if buf==NULL. */
 int64_t rt1w_format_ppm(const double* means, uint32_t width, uint32_t height, char* buf, uint64_t cap);
+
+/* sizeof of the ABI structs as this library was compiled (bindings check their own layout against it):
+ * 0 rt1w_render_params, 1 rt1w_stats, 2 rt1w_scene_info, 3 rt1w_specialise_info; 0 for anything else */
+uint32_t rt1w_abi_sizeof(int what);
 
 /* ---- diagnostics ---- */
 /* evaluates the numerical contract (include/rt1w_num.h) ON THE DEVICE for n inputs:

@@ -44,7 +44,7 @@ template <class Cfg>
 static void run_path(const RtSceneView& sc, const RtFrame& f, uint32_t px, uint32_t py, uint32_t s, HostStack& stk,
                      RtV3& sum, uint64_t& segs) {
     RtPath path;
-    rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+    rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
     while (path.alive) {
         segs += path.depth_left != 0u ? 1u : 0u;
         RtGlobalNodes ns{sc.nodes};

@@ -36,6 +36,7 @@ OUT_SUM = 1
 UNSORTED = 2
 LDS_NODES = 4
 GENERIC = 8  # do not use a scene-specialised kernel for this render
+OUT_FRAME = 32  # rt1w_render: `out` is the whole image; only the tile's pixels are written, at their image positions
 WAVEFRONT = 16  # big scenes: path state queued in HBM, trace / shade kernels per bounce
 SPECIALISE_CACHED_ONLY = 1
 
@@ -49,7 +50,7 @@ class Rt1wError(RuntimeError):
 class RenderParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
-        "max_depth", "global_seed", "chunk", "flags")]
+        "max_depth", "global_seed", "chunk", "flags", "strip_rows", "strip_period", "precision", "reserved")]
 
 
 class SpecialiseInfo(C.Structure):
@@ -127,12 +128,22 @@ _sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(S
 _sig("rt1w_render_u8", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, _P, C.c_uint32, C.c_uint32)
 _sig("rt1w_render_rows", C.c_int, _P, C.POINTER(RenderParams), C.c_uint32, C.c_int, _P, PROGRESS_FN, _P, C.POINTER(Stats))
+_sig("rt1w_abi_sizeof", C.c_uint32, C.c_int)
+_sig("rt1w_host_alloc", C.c_int, C.c_uint64, C.POINTER(_P))
+_sig("rt1w_host_free", C.c_int, _P)
+_sig("rt1w_host_register", C.c_int, _P, C.c_uint64)
+_sig("rt1w_host_unregister", C.c_int, _P)
 _sig("rt1w_resolve", C.c_int, _P, C.c_uint64, C.c_uint32, _P)
 _sig("rt1w_quantize", C.c_int, _P, C.c_uint64, _P)
 _sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
 _sig("rt1w_debug_eval", C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64)
 _sig("rt1w_debug_aabb", C.c_int, _P, _P, _P, _P, C.c_uint64)
 _sig("rt1w_debug_stamps", C.c_int, _P, C.POINTER(C.c_uint64 * 16), C.c_int)
+
+
+for _i, _t in enumerate((RenderParams, Stats, SceneInfo, SpecialiseInfo)):
+    if _lib.rt1w_abi_sizeof(_i) != C.sizeof(_t):
+        raise ImportError(f"librt1w.so and this binding disagree on the layout of {_t.__name__}: rebuild the library")
 
 
 def last_error():
@@ -317,10 +328,12 @@ class Context:
     __del__ = close
 
     @staticmethod
-    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False):
+    def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False,
+                strips=None, out_frame=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        flags = (OUT_SUM if out_sum else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (((variant + 1) << 8) if variant is not None else 0)
-        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags)
+        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        sr, sp = strips if strips is not None else (0, 0)
+        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp)
 
     def specialise(self, cached_only=False):
         """Load (from the kernel cache) or compile (hiprtc, 3-5 s) the kernel specialised for this scene's topology
@@ -338,10 +351,20 @@ class Context:
         return rc == 0 and bool(info.active)
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-               variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False):
-        """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict)."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront)
-        out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
+               variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False, strips=None, out=None, frame=None):
+        """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict).
+        strips=(strip_rows, strip_period): row-interleaved tile (tile row r = image row y0 + r//strip_rows*strip_period +
+        r%strip_rows).  out: caller's array for the packed tile (e.g. pinned_empty).  frame: caller's WHOLE image
+        [height, width, 3]; the tile's pixels are written at their image positions (RT1W_OUT_FRAME) and `frame` is returned."""
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront,
+                         strips, frame is not None)
+        if frame is not None:
+            assert frame.dtype == np.float64 and frame.shape == (height, width, 3) and frame.flags.c_contiguous
+            out = frame
+        elif out is None:
+            out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.float64)
+        else:
+            assert out.dtype == np.float64 and out.shape == (p.tile_h, p.tile_w, 3) and out.flags.c_contiguous
         st = Stats()
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
@@ -396,6 +419,38 @@ class Context:
         out = np.empty_like(a)
         _ck(_lib.rt1w_debug_eval(self._h, fn, a.ctypes.data_as(_P), b.ctypes.data_as(_P), out.ctypes.data_as(_P), a.size))
         return out
+
+
+class _Pinned:
+    def __init__(self, ptr): self.ptr = ptr
+    def __del__(self):
+        if self.ptr: _lib.rt1w_host_free(self.ptr); self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array over page-locked host memory (rt1w_host_alloc): device->host copies into it run at full PCIe rate."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = _P()
+    _ck(_lib.rt1w_host_alloc(n, C.byref(p)))
+    keep = _Pinned(p)
+    buf = (C.c_uint8 * n).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    _PINNED_KEEP[id(buf)] = keep
+    import weakref
+    weakref.finalize(buf, _PINNED_KEEP.pop, id(buf), None)
+    return a
+
+
+_PINNED_KEEP = {}
+
+
+def host_register(array):
+    """Pin memory the caller owns (e.g. a shared-memory mapping several single-GPU processes fill)."""
+    _ck(_lib.rt1w_host_register(C.c_void_p(array.ctypes.data), array.nbytes))
+
+
+def host_unregister(array):
+    _ck(_lib.rt1w_host_unregister(C.c_void_p(array.ctypes.data)))
 
 
 def resolve(sums, spp):

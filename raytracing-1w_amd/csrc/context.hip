@@ -126,7 +126,7 @@ __global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVE
                 }
             }
             if (!have) break; /* no work left: this lane retires */
-            rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+            rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
             RT_STAMP(1);
         }
         segs += path.depth_left != 0u ? 1ull : 0ull;
@@ -285,6 +285,16 @@ int validate(const rt1w_context* c, const rt1w_render_params* p) {
         rt1w::set_error("tile outside the image"); return RT1W_ERR_INVALID;
     }
     if (p->spp == 0) { rt1w::set_error("spp must be > 0"); return RT1W_ERR_INVALID; }
+    if ((p->strip_rows == 0) != (p->strip_period == 0) || p->strip_period < p->strip_rows) {
+        rt1w::set_error("strip_rows / strip_period: both 0, or 0 < strip_rows <= strip_period"); return RT1W_ERR_INVALID;
+    }
+    if (p->reserved != 0u) { rt1w::set_error("rt1w_render_params.reserved must be 0"); return RT1W_ERR_INVALID; }
+    if (p->precision != RT1W_PRECISION_F64) { rt1w::set_error("unknown precision"); return RT1W_ERR_UNSUPPORTED; }
+    if (p->strip_rows) {
+        const uint64_t last = (uint64_t)p->tile_h - 1u;
+        const uint64_t j = (uint64_t)p->y0 + (last / p->strip_rows) * p->strip_period + last % p->strip_rows;
+        if (j >= p->height) { rt1w::set_error("interleaved tile: last strip outside the image"); return RT1W_ERR_INVALID; }
+    }
     if ((uint64_t)p->sample_offset + p->spp > 0xFFFFFFFFull) { rt1w::set_error("sample index overflow"); return RT1W_ERR_INVALID; }
     return RT1W_OK;
 }
@@ -321,6 +331,7 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     f.x0 = p->x0; f.y0 = p->y0; f.tile_w = p->tile_w; f.tile_h = p->tile_h;
     f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth;
     f.global_seed = p->global_seed;
+    f.strip_rows = p->strip_rows; f.strip_period = p->strip_period;
     f.chunk = p->chunk ? p->chunk : rt1w_default_chunk(p->tile_w, p->tile_h, p->spp);
     if (f.chunk > f.spp) f.chunk = f.spp;
     f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
@@ -404,7 +415,16 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
     int rc = rt1w::jit_get_code(c->jit_src, allow_compile, code, info);
     c->jit_key = info.key;
     if (rc < 0) { rt1w::set_error("specialised kernel: " + info.message); return rc; }
-    if (!hip_ok(hipModuleLoadData(&c->jit_mod, code.data()), "hipModuleLoadData(specialised kernel)")) { c->jit_mod = nullptr; return RT1W_ERR_DEVICE; }
+    if (!hip_ok(hipModuleLoadData(&c->jit_mod, code.data()), "hipModuleLoadData(specialised kernel)")) {
+        c->jit_mod = nullptr;
+        if (!info.from_cache) return RT1W_ERR_DEVICE;
+        /* a cached object the driver refuses (truncated, foreign toolchain): forget it and, if allowed, compile afresh */
+        rt1w::jit_invalidate(info);
+        if (!allow_compile) return RT1W_ERR_DEVICE;
+        rc = rt1w::jit_get_code(c->jit_src, true, code, info, true);
+        if (rc < 0) { rt1w::set_error("specialised kernel: " + info.message); return rc; }
+        if (!hip_ok(hipModuleLoadData(&c->jit_mod, code.data()), "hipModuleLoadData(specialised kernel)")) { c->jit_mod = nullptr; return RT1W_ERR_DEVICE; }
+    }
     hipFunction_t fn = nullptr;
     if (!hip_ok(hipModuleGetFunction(&fn, c->jit_mod, "rt_jit_sorted"), "hipModuleGetFunction")) {
         (void)hipModuleUnload(c->jit_mod); c->jit_mod = nullptr; return RT1W_ERR_DEVICE;
@@ -666,6 +686,7 @@ int rt1w_render_device(rt1w_context* c, const rt1w_render_params* p, void* d_out
     int rc = validate(c, p);
     if (rc < 0) return rc;
     if (!d_out_rgb) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
+    if (p->flags & RT1W_OUT_FRAME) { rt1w::set_error("RT1W_OUT_FRAME is a host-output mode (rt1w_render)"); return RT1W_ERR_INVALID; }
     if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     auto t0 = std::chrono::steady_clock::now();
     rc = render_common(c, p, (double*)d_out_rgb, stats);
@@ -678,6 +699,7 @@ int rt1w_render_u8(rt1w_context* c, const rt1w_render_params* p, uint8_t* out_rg
     if (rc < 0) return rc;
     if (!out_rgb8) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
     if (p->flags & RT1W_OUT_SUM) { rt1w::set_error("RT1W_OUT_SUM has no 8-bit form"); return RT1W_ERR_INVALID; }
+    if ((p->flags & RT1W_OUT_FRAME) || p->strip_rows) { rt1w::set_error("rt1w_render_u8 takes contiguous tiles only"); return RT1W_ERR_INVALID; }
     if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     auto t0 = std::chrono::steady_clock::now();
     size_t npix = (size_t)p->tile_w * p->tile_h;
@@ -705,6 +727,7 @@ int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t stri
     if (!out) { rt1w::set_error("null output"); return RT1W_ERR_INVALID; }
     if (format != RT1W_ROWS_F64 && format != RT1W_ROWS_U8) { rt1w::set_error("unknown output format"); return RT1W_ERR_INVALID; }
     if (format == RT1W_ROWS_U8 && (p->flags & RT1W_OUT_SUM)) { rt1w::set_error("RT1W_OUT_SUM has no 8-bit form"); return RT1W_ERR_INVALID; }
+    if ((p->flags & RT1W_OUT_FRAME) || p->strip_rows) { rt1w::set_error("rt1w_render_rows takes contiguous tiles only"); return RT1W_ERR_INVALID; }
     if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t H = p->tile_h, W = p->tile_w;
@@ -823,10 +846,51 @@ int rt1w_render(rt1w_context* c, const rt1w_render_params* p, double* out_rgb, r
     }
     rc = render_common(c, p, c->d_out, stats);
     if (rc < 0) return rc;
-    if (!hip_ok(hipMemcpy(out_rgb, c->d_out, bytes, hipMemcpyDeviceToHost), "framebuffer copy")) return RT1W_ERR_DEVICE;
+    if (p->flags & RT1W_OUT_FRAME) {
+        /* the tile's rows to their places in the caller's whole-image buffer: one copy per strip (a strip of full-width rows
+         * is contiguous in both), queued on the stream, one wait */
+        hipStream_t st = c->lane[0].stream;
+        const size_t px = 3 * sizeof(double);
+        const uint32_t srows = p->strip_rows ? p->strip_rows : p->tile_h;
+        for (uint32_t r = 0; r < p->tile_h; r += srows) {
+            const uint32_t rows = p->tile_h - r < srows ? p->tile_h - r : srows;
+            const uint64_t j = p->strip_rows ? (uint64_t)p->y0 + (uint64_t)(r / srows) * p->strip_period : (uint64_t)p->y0 + r;
+            double* dst = out_rgb + (j * p->width + p->x0) * 3u;
+            const double* src = c->d_out + (size_t)r * p->tile_w * 3u;
+            hipError_t e = (p->tile_w == p->width)
+                ? hipMemcpyAsync(dst, src, (size_t)rows * p->tile_w * px, hipMemcpyDeviceToHost, st)
+                : hipMemcpy2DAsync(dst, (size_t)p->width * px, src, (size_t)p->tile_w * px, (size_t)p->tile_w * px, rows, hipMemcpyDeviceToHost, st);
+            if (!hip_ok(e, "framebuffer copy")) return RT1W_ERR_DEVICE;
+        }
+        if (!hip_ok(hipStreamSynchronize(st), "framebuffer copy")) return RT1W_ERR_DEVICE;
+    } else if (!hip_ok(hipMemcpy(out_rgb, c->d_out, bytes, hipMemcpyDeviceToHost), "framebuffer copy")) return RT1W_ERR_DEVICE;
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT1W_OK;
 }
+
+uint32_t rt1w_abi_sizeof(int what) {
+    switch (what) {
+        case 0: return (uint32_t)sizeof(rt1w_render_params);
+        case 1: return (uint32_t)sizeof(rt1w_stats);
+        case 2: return (uint32_t)sizeof(rt1w_scene_info);
+        case 3: return (uint32_t)sizeof(rt1w_specialise_info);
+        default: return 0u;
+    }
+}
+
+int rt1w_host_alloc(uint64_t bytes, void** out) {
+    if (!out || bytes == 0) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    *out = nullptr;
+    if (!hip_ok(hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable), "hipHostMalloc")) return RT1W_ERR_NOMEM;
+    return RT1W_OK;
+}
+int rt1w_host_free(void* p) { if (p && !hip_ok(hipHostFree(p), "hipHostFree")) return RT1W_ERR_DEVICE; return RT1W_OK; }
+int rt1w_host_register(void* p, uint64_t bytes) {
+    if (!p || bytes == 0) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable), "hipHostRegister")) return RT1W_ERR_DEVICE;
+    return RT1W_OK;
+}
+int rt1w_host_unregister(void* p) { if (p && !hip_ok(hipHostUnregister(p), "hipHostUnregister")) return RT1W_ERR_DEVICE; return RT1W_OK; }
 
 int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* out_fast, uint64_t n) {
     if (!c || !in || !out_literal || !out_fast) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }

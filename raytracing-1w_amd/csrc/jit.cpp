@@ -44,6 +44,7 @@ struct Hiprtc {
     hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
     hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
     hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
+    hiprtcResult (*Version)(int*, int*) = nullptr; /* optional */
     bool tried = false, ok = false;
 };
 Hiprtc g_rtc;
@@ -63,6 +64,7 @@ bool load_hiprtc(std::string& err) {
     RT_SYM(GetCode, "hiprtcGetCode")
     RT_SYM(DestroyProgram, "hiprtcDestroyProgram")
 #undef RT_SYM
+    *(void**)(&g_rtc.Version) = dlsym(g_rtc.lib, "hiprtcVersion");
     g_rtc.ok = true;
     return true;
 }
@@ -88,6 +90,15 @@ std::vector<std::string> options() {
         }
     }
     return o;
+}
+
+/* the compiler's identity: a code object cached by another hiprtc / ROCm release must not be picked up */
+std::string compiler_id() {
+    std::string err;
+    if (!load_hiprtc(err)) return "hiprtc-absent";
+    int major = 0, minor = 0;
+    if (g_rtc.Version && g_rtc.Version(&major, &minor) == 0) return "hiprtc-" + std::to_string(major) + "." + std::to_string(minor);
+    return "hiprtc-unknown";
 }
 
 bool read_file(const std::string& path, std::vector<char>& out) {
@@ -168,6 +179,7 @@ std::string jit_key(const std::string& source) {
     h = fnv1a(h, source);
     for (int i = 0; i < RT_JIT_N_HEADERS; ++i) { h = fnv1a(h, rt_jit_header_names[i], std::strlen(rt_jit_header_names[i])); h = fnv1a(h, rt_jit_header_texts[i], std::strlen(rt_jit_header_texts[i])); }
     for (const std::string& o : options()) h = fnv1a(h, o);
+    h = fnv1a(h, compiler_id());
     char buf[32];
     std::snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
     return buf;
@@ -200,14 +212,21 @@ int jit_compile(const std::string& source, std::vector<char>& code, std::string&
     return RT1W_OK;
 }
 
-int jit_get_code(const std::string& src, bool allow_compile, std::vector<char>& code, JitInfo& info) {
+/* a cached code object the driver refused (truncated file, foreign toolchain): drop it from the user cache so that the next
+ * request compiles again; files under <libdir>/kernels belong to the installation and are left alone */
+void jit_invalidate(const JitInfo& info) {
+    const std::string u = user_cache_dir();
+    if (!info.path.empty() && !u.empty() && info.path.compare(0, u.size(), u) == 0) std::remove(info.path.c_str());
+}
+
+int jit_get_code(const std::string& src, bool allow_compile, std::vector<char>& code, JitInfo& info, bool ignore_cache) {
     info = JitInfo();
     if (src.empty()) { info.message = "scene is not eligible (more than RT_JIT_MAX_NODES nodes)"; return RT1W_ERR_UNSUPPORTED; }
     info.key = jit_key(src);
     const std::string name = "/sweep_" + info.key + ".hsaco";
     const std::string dirs[2] = {install_cache_dir(), user_cache_dir()};
     for (const std::string& d : dirs) {
-        if (d.empty()) continue;
+        if (d.empty() || ignore_cache) continue;
         if (read_file(d + name, code)) { info.from_cache = true; info.path = d + name; return RT1W_OK; }
     }
     if (!allow_compile) { info.message = "no cached kernel for this topology"; return RT1W_ERR_STATE; }

@@ -10,7 +10,7 @@
 namespace rt1w {
 
 struct JitInfo {
-    std::string key;      /* hash of source + embedded headers + compiler options */
+    std::string key;      /* hash of source + embedded headers + compiler options + hiprtc version */
     std::string path;     /* cache file the code came from / went to ("" if none) */
     std::string message;  /* why it failed (compiler log, ...) */
     bool from_cache = false;
@@ -22,7 +22,8 @@ std::string jit_source(const rt1w_scene& s);          /* the generated translati
 std::string jit_key(const std::string& source);
 int jit_compile(const std::string& source, std::vector<char>& code, std::string& log); /* hiprtc; RT1W_ERR_UNSUPPORTED without libhiprtc */
 /* code object for a generated source: <libdir>/kernels, then the user cache, then (if allowed) the compiler */
-int jit_get_code(const std::string& source, bool allow_compile, std::vector<char>& code, JitInfo& info);
+int jit_get_code(const std::string& source, bool allow_compile, std::vector<char>& code, JitInfo& info, bool ignore_cache = false);
+void jit_invalidate(const JitInfo& info); /* unlink a cached object the driver refused (user cache only) */
 /* build step: compile into `dir` unless already there */
 int jit_precompile_to(const rt1w_scene& s, const std::string& dir, JitInfo& info);
 

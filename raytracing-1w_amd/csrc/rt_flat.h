@@ -137,7 +137,16 @@ struct RtFrame {
     uint32_t global_seed;
     uint32_t chunk;               /* samples per work item; pixel sum = sum over chunks of chunk sums */
     uint32_t n_chunks;
+    /* row-interleaved tile (image tiling over GPUs: strips of `strip_rows` image rows dealt round-robin): tile row r is
+     * image row y0 + (r / strip_rows) * strip_period + r % strip_rows.  strip_rows == 0: contiguous rows y0 + r. */
+    uint32_t strip_rows, strip_period;
 };
+/* image row j (the reference's row index, main.rs:957-964) of tile row py */
+RT_HD uint32_t rt_frame_row(const RtFrame& f, uint32_t py) {
+    if (f.strip_rows == 0u) return f.y0 + py;
+    const uint32_t k = py / f.strip_rows;
+    return f.y0 + k * f.strip_period + (py - k * f.strip_rows);
+}
 
 #define RT_STACK_CAP 32      /* traversal stack entries per lane (LDS) */
 #define RT_SWEEP_MAX_NODES 64 /* scenes up to this many nodes use the stackless wave-uniform sweep */

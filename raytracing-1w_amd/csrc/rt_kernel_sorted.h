@@ -118,7 +118,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
                 }
             }
             if (!have) retired = true;
-            else rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s, path);
+            else rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
         }
         RT_STAMP(1);
         /* 2. closest hit + class */

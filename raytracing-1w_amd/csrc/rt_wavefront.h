@@ -32,7 +32,7 @@ __global__ void wf_generate(RtSceneView sc, RtFrame f, WfPath* __restrict__ path
     const uint32_t pixel = (uint32_t)(gid % npix);
     const uint32_t px = pixel % f.tile_w, py = pixel / f.tile_w;
     WfPath P;
-    rt_path_begin(sc, f, f.x0 + px, f.y0 + py, f.sample_offset + s0 + s_local, P.p);
+    rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s0 + s_local, P.p);
     P.t = 0.0; P.prim = RT_NONE; P.scope = RT_NONE;
     paths[gid] = P;
     queue[gid] = (uint32_t)gid;

@@ -35,6 +35,58 @@ def row_strips(height, world_size, rank, strip_rows=STRIP_ROWS):
     return out
 
 
+def interleaved_tile(height, world_size, rank, strip_rows=STRIP_ROWS):
+    """The same partition as row_strips, as ONE row-interleaved tile for rt1w_render_params:
+    (y0, tile_h, strip_rows, strip_period) -- tile row r is image row y0 + r//strip_rows*strip_period + r%strip_rows.
+    tile_h == 0: this rank owns nothing (more ranks than strips)."""
+    rows = sum(n for _, n in row_strips(height, world_size, rank, strip_rows))
+    return rank * strip_rows, rows, strip_rows, world_size * strip_rows
+
+
+class SharedFrame:
+    """One whole-image f64 frame [height, width, 3] in POSIX shared memory (/dev/shm), mapped by every rank of a node and
+    pinned for the GPU (rt1w_host_register): each rank's device->host copy writes its strips straight to their places
+    (RT1W_OUT_FRAME) -- that copy IS the host gather of the image-tiled job (north star: "host gather only; no RCCL");
+    nothing is stitched afterwards.  Rank 0 creates, the others attach after a barrier; rank 0 unlinks."""
+
+    def __init__(self, name, width, height, create, rt=None):
+        import mmap
+        import os
+        self.path = os.path.join("/dev/shm", name)
+        self.nbytes = width * height * 3 * 8
+        self.created = create
+        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        fd = os.open(self.path, flags, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, self.nbytes)
+            self._mm = mmap.mmap(fd, self.nbytes)
+        finally:
+            os.close(fd)
+        self.array = np.frombuffer(self._mm, dtype=np.float64).reshape(height, width, 3)
+        self._rt = rt
+        self._pinned = False
+        if rt is not None:
+            rt.host_register(self.array)
+            self._pinned = True
+
+    def close(self):
+        if self._pinned:
+            self._rt.host_unregister(self.array)
+            self._pinned = False
+        self.array = None
+        try:
+            self._mm.close()
+        except BufferError:
+            pass
+        if self.created:
+            import os
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+
+
 def sample_range(spp_total, world_size, rank):
     """(offset, count) of the contiguous sample range of `rank`; requires divisibility so that
     the summation order equals a single render with chunk = spp_total / world_size."""

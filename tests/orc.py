@@ -125,7 +125,7 @@ class OracleScene:
 
 class Frame(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
-                                          "max_depth", "global_seed", "chunk", "n_chunks")]
+                                          "max_depth", "global_seed", "chunk", "n_chunks", "strip_rows", "strip_period")]
 
 
 B.orcflat_render.restype = C.c_int
@@ -144,7 +144,7 @@ def declare_flat(lib):
 
 
 def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-                threads=None, variant=None, lib=None):
+                threads=None, variant=None, lib=None, strips=None):
     """CPU build of the kernel core over the flat arrays of a committed rt1w scene.
     `variant`: kernel variant (0..3, see rt_flat.h); default = the one the library picks."""
     x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
@@ -154,7 +154,7 @@ def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offse
     info = scene.info()
     if variant is None:
         variant = info["variant"]
-    f = Frame(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, 0)
+    f = Frame(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, 0, *(strips or (0, 0)))
     out = np.empty((th, tw, 3), dtype=np.float64)
     seg = C.c_uint64()
     mx = C.c_uint32()

@@ -26,6 +26,27 @@ def test_library_exports_every_declared_symbol(rt):
         assert hasattr(lib, n), f"{n} is declared in include/rt1w.h but not exported"
 
 
+def test_integration_rust_block_declares_every_entry_of_the_header():
+    """INTEGRATION.md section 2 claims to mirror include/rt1w.h one to one: the `extern "C"` block must name exactly the
+    functions the header declares, and its #[repr(C)] structs must have the header's fields in the header's order."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index("## 2."):md.index("## 3.")]
+    rust = sorted(set(re.findall(r"pub fn (rt1w_[a-z0-9_]+)\(", block)))
+    assert rust == declared_functions(), (set(declared_functions()) - set(rust), set(rust) - set(declared_functions()))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt1w.h")).read(), flags=re.S)
+    for name in ("rt1w_render_params", "rt1w_stats", "rt1w_scene_info", "rt1w_specialise_info"):
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", hdr, flags=re.S).group(1)
+        c_fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                c_fields += [re.sub(r"\[.*?\]", "", f).strip().split()[-1] for f in decl.split(",")]
+        rs = re.search(r"pub struct " + name + r" \{(.*?)\n\}", block, flags=re.S).group(1)
+        rs = re.sub(r"//[^\n]*", "", rs)
+        r_fields = re.findall(r"pub ([a-z0-9_]+):", rs)
+        assert r_fields == c_fields, (name, r_fields, c_fields)
+
+
 def test_every_declared_entry_cites_the_reference():
     src = open(os.path.join(ROOT, "include", "rt1w.h")).read()
     for fn in ("rt1w_hittable_sphere", "rt1w_hittable_bvh", "rt1w_render", "rt1w_scene_set_camera", "rt1w_quantize"):
@@ -35,8 +56,10 @@ def test_every_declared_entry_cites_the_reference():
 
 
 def test_struct_layouts_match_between_python_and_c(rt):
-    assert C.sizeof(rt.RenderParams) == 48 and C.sizeof(rt.Stats) == 56 and C.sizeof(rt.SceneInfo) == 56
+    assert C.sizeof(rt.RenderParams) == 64 and C.sizeof(rt.Stats) == 56 and C.sizeof(rt.SceneInfo) == 56
     assert C.sizeof(rt.SpecialiseInfo) == 48
+    for i, t in enumerate((rt.RenderParams, rt.Stats, rt.SceneInfo, rt.SpecialiseInfo)):
+        assert rt._lib.rt1w_abi_sizeof(i) == C.sizeof(t)
     assert orc.B.orcflat_sizeof(0) == 96 and orc.B.orcflat_sizeof(1) == 48 and orc.B.orcflat_sizeof(2) == 48
     assert orc.B.orcflat_sizeof(3) == 9216 and orc.B.orcflat_sizeof(5) == C.sizeof(orc.Frame)
 

@@ -496,3 +496,95 @@ def test_wavefront_form_is_bit_identical(rt, gpu_ctx_factory):
     small = gpu_ctx_factory(rt.Scene.reference(5, build_seed=1))
     c, sc_ = small.render(32, 32, 4, wavefront=True)      # sweep scenes keep their own kernels: the flag is ignored
     assert sc_["sorted"] != 8
+
+
+def test_interleaved_strips_and_shared_host_frame(rt, gpu_ctx_factory):
+    """Image tiling over GPUs as ONE launch per GPU (rt1w_render_params.strip_rows / strip_period) and the host gather
+    as device->host copies into one pinned whole-image frame (RT1W_OUT_FRAME): for 1, 2, 3 and 8 ranks the ranks'
+    tiles, written by the library to their image positions, rebuild the single-render frame bit for bit; the packed form
+    equals the rows it names; a narrow tile lands through the 2-D copy; bad parameters are refused."""
+    import importlib
+    sh = importlib.import_module("raytracing-1w_amd.sharding")
+    sc = rt.Scene.reference(5, build_seed=1)
+    ctx = gpu_ctx_factory(sc)
+    W, H, spp = 96, 88, 8                      # 88 rows: five full 16-row strips and a ragged one
+    chunk = rt.default_chunk(W, H, spp)
+    full, _ = ctx.render(W, H, spp, chunk=chunk)
+    for world in (1, 2, 3, 8):
+        frame = rt.pinned_empty((H, W, 3))
+        frame[:] = -1.0
+        for rank in range(world):
+            y0, rows, srows, period = sh.interleaved_tile(H, world, rank)
+            if rows == 0:
+                continue
+            ctx.render(W, H, spp, tile=(0, y0, W, rows), strips=(srows, period), frame=frame, chunk=chunk)
+            packed, _ = ctx.render(W, H, spp, tile=(0, y0, W, rows), strips=(srows, period), chunk=chunk)
+            mine = [y for (sy, n) in sh.row_strips(H, world, rank) for y in range(sy, sy + n)]
+            assert np.array_equal(packed, full[mine])
+        assert np.array_equal(frame, full), world
+    # contiguous narrow tile into a frame (2-D copy) + untouched remainder
+    frame = rt.pinned_empty((H, W, 3))
+    frame[:] = -1.0
+    ctx.render(W, H, spp, tile=(10, 20, 30, 7), frame=frame, chunk=chunk)
+    assert np.array_equal(frame[20:27, 10:40], full[20:27, 10:40])
+    frame[20:27, 10:40] = -1.0
+    assert (frame == -1.0).all()
+    # pageable frames work too (slower copy, same bytes)
+    plain = np.full((H, W, 3), -1.0)
+    ctx.render(W, H, spp, tile=(0, 16, W, 16), frame=plain, chunk=chunk)
+    assert np.array_equal(plain[16:32], full[16:32]) and (plain[:16] == -1.0).all()
+    for bad in ((16, 0), (0, 16), (16, 8)):
+        with pytest.raises(rt.Rt1wError):
+            ctx.render(W, H, spp, tile=(0, 0, W, 16), strips=bad)
+    with pytest.raises(rt.Rt1wError):          # the last strip would lie outside the image
+        ctx.render(W, H, spp, tile=(0, 80, W, 32), strips=(16, 32))
+
+
+def test_device_u8_equals_the_oracles_own_quantiser(rt, gpu_ctx_factory):
+    """The integer pixel output of the product (quantised on the device) against the LITERAL oracle's frame pushed
+    through the oracle's own quantiser (color.rs:56-65 restated in oracle.cpp) -- no product code on the expected side."""
+    for arm, (W, H, spp) in ((5, (64, 64, 16)), (0, (96, 64, 8)), (7, (64, 64, 16))):
+        ctx = gpu_ctx_factory(rt.Scene.reference(arm, build_seed=1))
+        u8, _ = ctx.render_u8(W, H, spp)
+        o = orc.OracleScene(arm, build_seed=1)
+        lit, _ = o.render(W, H, spp)
+        assert np.array_equal(u8, o.quantize(lit)[::-1]), arm
+
+
+def test_c5_full_size_3840x2160_10000spp(rt, gpu_ctx_factory):
+    """BASELINE C5 at FULL size on one GPU (8.29e10 paths, ~22 s) through rt1w_render_rows (strips, f64 means): crops
+    against the CPU core build, NaN-free, the strip-wise frame's rows equal a one-shot tile render of the same rows."""
+    sc = rt.Scene.reference(5, build_seed=1, aspect_ratio=16.0 / 9.0)
+    ctx = gpu_ctx_factory(sc)
+    W, H, spp = 3840, 2160, 10000
+    seen = []
+    full, st = ctx.render_rows(W, H, spp, progress=lambda d, t: seen.append((d, t)) and False)
+    assert st["paths"] == W * H * spp and seen and seen[-1] == (H, H)
+    assert np.isfinite(full).all() and 3.0 < st["segments"] / st["paths"] < 3.6
+    chunk = rt.default_chunk(W, H, spp)
+    for tile in ((1916, 1080, 4, 2), (8, 8, 2, 2)):
+        b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=chunk)
+        x0, y0, w, h = tile
+        assert np.array_equal(full[y0:y0 + h, x0:x0 + w], b)
+    one, _ = ctx.render(W, H, spp, tile=(0, 1072, W, 16), chunk=chunk)
+    assert np.array_equal(one, full[1072:1088])
+    print(f"C5 full size: {st['total_ms'] / 1e3:.1f} s, {st['paths'] / st['total_ms'] / 1e3:.0f} Mpaths/s incl. D2H, "
+          f"{st['segments'] / st['paths']:.3f} segments/path")
+
+
+def test_c4_full_size_800x800_10000spp(rt, gpu_ctx_factory):
+    """BASELINE C4 at FULL size on one GPU (6.4e9 paths): the whole frame at the reference's own 10 000 spp
+    (main.rs:917-919) against next_week.png on its comparable blocks, tighter than the 200-spp test, + a crop against
+    the CPU core build."""
+    from test_golden import final_png_block_check
+    sc = rt.Scene.reference(7, build_seed=1)
+    ctx = gpu_ctx_factory(sc)
+    W = H = 800
+    spp = 10000
+    full, st = ctx.render_rows(W, H, spp)
+    assert st["paths"] == W * H * spp
+    final_png_block_check(full, 0.10, 0.02)
+    tile = (392, 300, 4, 2)
+    b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=rt.default_chunk(W, H, spp))
+    assert np.array_equal(full[300:302, 392:396], b, equal_nan=True)
+    print(f"C4 full size: {st['total_ms'] / 1e3:.1f} s, {st['paths'] / st['total_ms'] / 1e3:.0f} Mpaths/s incl. D2H")

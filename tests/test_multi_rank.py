@@ -36,7 +36,26 @@ def _worker(rank, world, port, mode, q):
                                  threads=2)
         return img
 
-    if mode == "rows":
+    if mode == "frame":
+        # what bench.py --gpus N does: ONE row-interleaved tile per rank (rt1w_render_params.strip_rows/strip_period), every
+        # rank writes its strips into one shared host frame, nothing is stitched afterwards
+        y0, rows, srows, period = sh.interleaved_tile(H, world, rank)
+        fr = sh.SharedFrame(f"rt1w_test_{port}", W, H, rank == 0) if rank == 0 else None
+        dist.barrier()
+        if rank != 0:
+            fr = sh.SharedFrame(f"rt1w_test_{port}", W, H, False)
+        packed, _ = orc.flat_render(sc, W, H, SPP, tile=(0, y0, W, rows), strips=(srows, period), chunk=SPP // world, threads=2)
+        pos = 0
+        for (sy, n) in sh.row_strips(H, world, rank):
+            fr.array[sy:sy + n] = packed[pos:pos + n]
+            pos += n
+        assert pos == rows
+        dist.barrier()
+        if rank == 0:
+            q.put(fr.array.copy())
+        dist.barrier()
+        fr.close()
+    elif mode == "rows":
         _, packed = sh.render_rows(render_fn, W, H, SPP, world, rank)
         parts = sh.gather_to_rank0(packed)
         if rank == 0:
@@ -51,7 +70,7 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["rows", "samples"])
+@pytest.mark.parametrize("mode", ["rows", "samples", "frame"])
 def test_two_rank_sharded_render_equals_single(rt, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -80,6 +99,11 @@ def test_row_strips_partition_every_row_once():
             for y, n in rows:
                 covered[y:y + n] += 1
             assert np.all(covered == 1)
+            for r in range(world):                   # the one-launch form of the same partition
+                y0, n_rows, srows, period = sh.interleaved_tile(height, world, r)
+                mine = [y for (sy, n) in sh.row_strips(height, world, r) for y in range(sy, sy + n)]
+                assert n_rows == len(mine)
+                assert [y0 + (t // srows) * period + t % srows for t in range(n_rows)] == mine
     with pytest.raises(ValueError):
         sh.sample_range(10, 4, 0)
     assert [sh.sample_range(1000, 8, r) for r in (0, 7)] == [(0, 125), (875, 125)]
