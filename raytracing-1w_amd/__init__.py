@@ -393,9 +393,10 @@ class Context:
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
     def render_device(self, d_ptr, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0,
-                      out_sum=False, variant=None, unsorted=False, generic=False):
-        """Same, into device memory `d_ptr` (int address, e.g. torch tensor .data_ptr())."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, False, generic)
+                      out_sum=False, variant=None, unsorted=False, generic=False, strips=None):
+        """Same, into device memory `d_ptr` (int address, e.g. torch tensor .data_ptr()); packed tile rows."""
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, False, generic,
+                         False, strips)
         st = Stats()
         _ck(_lib.rt1w_render_device(self._h, C.byref(p), C.c_void_p(d_ptr), C.byref(st)))
         return {n: getattr(st, n) for n, _ in Stats._fields_}

@@ -244,11 +244,14 @@ struct rt1w_context {
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
-    /* wavefront form (rt_wavefront.h): path records, two queues, per-sample radiance of one chunk, counters */
-    void* wf_paths = nullptr; uint32_t* wf_queue[2] = {nullptr, nullptr}; double* wf_rad = nullptr;
-    unsigned long long* wf_counters = nullptr; unsigned long long* wf_hcounters = nullptr;
-    size_t wf_paths_cap = 0, wf_rad_cap = 0;
-    int wf_grid[RT_N_VARIANTS] = {0, 0, 0, 0};
+    /* wavefront form (rt_wavefront.h): two SoA path queues, per-sample radiance of one pass, device-side counters */
+    WfQueue wf_q[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    double* wf_rad = nullptr;
+    WfCounters* wf_counters = nullptr; unsigned long long* wf_hcounters = nullptr;
+    size_t wf_cap = 0;
+    WfRecs wf_recs = {nullptr, 0.0, 1.0}; void* d_wf_recs = nullptr; /* walk records of the big scenes (null: not eligible) */
+    int wf_grid_trace[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wf_grid_shade[2] = {0, 0}, wf_grid_finish[2] = {0, 0};
+    uint32_t stack_need = 0;
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
     hipModule_t jit_mod = nullptr;
@@ -441,80 +444,102 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
     return RT1W_OK;
 }
 
-typedef void (*wf_trace_t)(RtSceneView, WfPath*, const uint32_t*, unsigned long long, unsigned long long*, uint32_t);
-typedef void (*wf_shade_t)(RtSceneView, WfPath*, const uint32_t*, unsigned long long, uint32_t*, unsigned long long*, double*, unsigned long long);
-static wf_trace_t const g_wf_trace[RT_N_VARIANTS] = {nullptr, nullptr, wf_trace<RtCfgV2>, wf_trace<RtCfgV3>};
-static wf_shade_t const g_wf_shade[RT_N_VARIANTS] = {nullptr, nullptr, wf_shade<RtCfgV2>, wf_shade<RtCfgV3>};
-#define RT_WF_PASS_PATHS (16ull << 20) /* paths in flight per pass: 16 Mi x 200 B = 3.4 GB of path records */
+/* ---- wavefront form (rt_wavefront.h) ---- */
+typedef void (*wf_trace_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, WfRecs);
+typedef void (*wf_shade_t)(RtSceneView, RtFrame, WfQueue, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
+/* trace kernels: [variant 2/3][scene has wrappers][stack capacity 16/32] */
+static wf_trace_t const g_wf_trace[2][2][2] = {
+    {{wf_trace<RtCfgV2, false, 16>, wf_trace<RtCfgV2, false, 32>}, {wf_trace<RtCfgV2, true, 16>, wf_trace<RtCfgV2, true, 32>}},
+    {{wf_trace<RtCfgV3, false, 16>, wf_trace<RtCfgV3, false, 32>}, {wf_trace<RtCfgV3, true, 16>, wf_trace<RtCfgV3, true, 32>}}};
+static wf_trace_t const g_wf_trace_lds[2][2] = {{wf_trace_lds<RtCfgV2, false>, wf_trace_lds<RtCfgV2, true>}, {wf_trace_lds<RtCfgV3, false>, wf_trace_lds<RtCfgV3, true>}};
+static wf_shade_t const g_wf_shade[2] = {wf_shade<RtCfgV2>, wf_shade<RtCfgV3>};
+typedef void (*wf_finish_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
+static wf_finish_t const g_wf_finish[2] = {wf_finish<RtCfgV2>, wf_finish<RtCfgV3>};
+#define RT_WF_PASS_PATHS (16ull << 20) /* paths in flight per pass: 2 queues x 16 Mi x 128 B = 4 GiB */
 
-/* the wavefront form of one render: per chunk of samples, passes of <= RT_WF_PASS_PATHS paths, per pass
- * generate -> (trace -> shade)* until the queue is empty; then the chunk's samples are summed in order */
+/* the wavefront form of one render: per chunk of samples, passes of <= RT_WF_PASS_PATHS paths; per pass
+ * generate -> (trace -> shade) x max_depth with the queue lengths kept on the device; then the pass's samples are added
+ * to the chunk sum in sample order */
 int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunch& L, double* d_out, rt1w_stats* stats) {
     RtLane& l = c->lane[0];
     const RtFrame& f = L.f;
     const unsigned long long npix = L.npix;
     const int v = L.variant;
-    if (!g_wf_trace[v]) { rt1w::set_error("the wavefront form exists for the stack-walk variants only"); return RT1W_ERR_INVALID; }
+    if (v < 2) { rt1w::set_error("the wavefront form exists for the stack-walk variants only"); return RT1W_ERR_INVALID; }
     if (npix > RT_WF_PASS_PATHS) { rt1w::set_error("wavefront form: tile larger than one pass (render it in strips)"); return RT1W_ERR_UNSUPPORTED; }
+    if (f.max_depth > WF_MAX_BOUNCES) { rt1w::set_error("wavefront form: max_depth above WF_MAX_BOUNCES"); return RT1W_ERR_UNSUPPORTED; }
+    if (!c->wf_recs.p) { rt1w::set_error("wavefront form: the scene's moving spheres do not share one shutter interval"); return RT1W_ERR_UNSUPPORTED; }
     const uint32_t s_pass_max = (uint32_t)(RT_WF_PASS_PATHS / npix);
-    const size_t paths_cap = (size_t)npix * (f.chunk < s_pass_max ? f.chunk : s_pass_max);
-    const size_t rad_cap = (size_t)npix * f.chunk;
-    if (paths_cap > c->wf_paths_cap) {
-        if (c->wf_paths) (void)hipFree(c->wf_paths);
-        for (int k = 0; k < 2; ++k) { if (c->wf_queue[k]) (void)hipFree(c->wf_queue[k]); c->wf_queue[k] = nullptr; }
-        c->wf_paths = nullptr; c->wf_paths_cap = 0;
-        if (!hip_ok(hipMalloc(&c->wf_paths, paths_cap * sizeof(WfPath)), "hipMalloc(path records)") ||
-            !hip_ok(hipMalloc((void**)&c->wf_queue[0], paths_cap * sizeof(uint32_t)), "hipMalloc(queue)") ||
-            !hip_ok(hipMalloc((void**)&c->wf_queue[1], paths_cap * sizeof(uint32_t)), "hipMalloc(queue)")) return RT1W_ERR_NOMEM;
-        c->wf_paths_cap = paths_cap;
-    }
-    if (rad_cap > c->wf_rad_cap) {
+    const uint32_t n_pass = (f.chunk + s_pass_max - 1u) / s_pass_max;      /* passes per chunk, of (nearly) equal size */
+    const uint32_t s_pass = (f.chunk + n_pass - 1u) / n_pass;
+    const size_t cap = (size_t)npix * s_pass;
+    if (cap > c->wf_cap) {
+        for (int k = 0; k < 2; ++k) {
+            if (c->wf_q[k].f) (void)hipFree(c->wf_q[k].f);
+            if (c->wf_q[k].u) (void)hipFree(c->wf_q[k].u);
+            c->wf_q[k] = WfQueue{nullptr, nullptr, 0};
+        }
         if (c->wf_rad) (void)hipFree(c->wf_rad);
-        c->wf_rad = nullptr; c->wf_rad_cap = 0;
-        if (!hip_ok(hipMalloc((void**)&c->wf_rad, rad_cap * 3 * sizeof(double)), "hipMalloc(sample radiance)")) return RT1W_ERR_NOMEM;
-        c->wf_rad_cap = rad_cap;
+        c->wf_rad = nullptr; c->wf_cap = 0;
+        for (int k = 0; k < 2; ++k) {
+            if (!hip_ok(hipMalloc((void**)&c->wf_q[k].f, cap * WF_NF * sizeof(double)), "hipMalloc(path queue)") ||
+                !hip_ok(hipMalloc((void**)&c->wf_q[k].u, cap * WU_NU * sizeof(uint32_t)), "hipMalloc(path queue)")) return RT1W_ERR_NOMEM;
+            c->wf_q[k].cap = cap;
+        }
+        if (!hip_ok(hipMalloc((void**)&c->wf_rad, cap * 3 * sizeof(double)), "hipMalloc(sample radiance)")) return RT1W_ERR_NOMEM;
+        c->wf_cap = cap;
     }
     if (!c->wf_counters) {
-        if (!hip_ok(hipMalloc((void**)&c->wf_counters, 4 * sizeof(unsigned long long)), "hipMalloc(counters)") ||
-            !hip_ok(hipHostMalloc((void**)&c->wf_hcounters, 4 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(counters)")) return RT1W_ERR_NOMEM;
+        if (!hip_ok(hipMalloc((void**)&c->wf_counters, sizeof(WfCounters)), "hipMalloc(counters)") ||
+            !hip_ok(hipHostMalloc((void**)&c->wf_hcounters, 2 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(counters)")) return RT1W_ERR_NOMEM;
     }
-    if (!c->wf_grid[v]) {
+    const bool lds_recs = c->n_nodes <= RT_WF_LDS_NODES && c->stack_need <= 16u && !getenv("RT1W_WF_NO_LDS");
+    const int tblock = lds_recs ? RT_WF_LDS_BLOCK : RT_BLOCK;
+    const wf_trace_t trace = lds_recs ? g_wf_trace_lds[v - 2][c->scope_depth > 0u ? 1 : 0]
+                                      : g_wf_trace[v - 2][c->scope_depth > 0u ? 1 : 0][c->stack_need <= 16u ? 0 : 1];
+    const wf_shade_t shade = g_wf_shade[v - 2];
+    const int gi = lds_recs ? 8 + (v - 2) * 2 + (c->scope_depth > 0u ? 1 : 0) : (v - 2) * 4 + (c->scope_depth > 0u ? 2 : 0) + (c->stack_need <= 16u ? 0 : 1);
+    if (!c->wf_grid_trace[gi] || !c->wf_grid_shade[v - 2]) {
+        int per_cu = 0, per_cu_s = 0;
+        hipDeviceProp_t prop;
+        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace, tblock, 0), "occupancy query") ||
+            !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, shade, RT_BLOCK, 0), "occupancy query") ||
+            !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
+        c->wf_grid_trace[gi] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+        c->wf_grid_shade[v - 2] = prop.multiProcessorCount * (per_cu_s < 1 ? 1 : per_cu_s) * 2; /* grid-stride; short blocks */
+    }
+    const int grid_t = c->wf_grid_trace[gi], grid_s = c->wf_grid_shade[v - 2];
+    const wf_finish_t finish = g_wf_finish[v - 2];
+    if (!c->wf_grid_finish[v - 2]) {
         int per_cu = 0;
         hipDeviceProp_t prop;
-        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_wf_trace[v], RT_BLOCK, 0), "occupancy query") ||
+        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finish, RT_BLOCK, 0), "occupancy query") ||
             !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
-        c->wf_grid[v] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+        c->wf_grid_finish[v - 2] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
     }
-    unsigned long long segments = 0;
-    const uint32_t refill = RT_WF_REFILL;
+    const uint32_t wf_bounces = f.max_depth < RT_WF_BOUNCES ? f.max_depth : RT_WF_BOUNCES;
+    if (!hip_ok(hipMemsetAsync(&c->wf_counters->segs, 0, sizeof(unsigned long long), l.stream), "counter reset")) return RT1W_ERR_DEVICE;
     (void)hipEventRecord(l.ev0, l.stream);
     for (uint32_t ch = 0; ch < f.n_chunks; ++ch) {
         const uint32_t s_begin = ch * f.chunk;
         const uint32_t s_cnt = s_begin + f.chunk < f.spp ? f.chunk : f.spp - s_begin;
-        for (uint32_t s0 = 0; s0 < s_cnt; s0 += s_pass_max) {
-            const uint32_t s_n = s_cnt - s0 < s_pass_max ? s_cnt - s0 : s_pass_max;
-            unsigned long long n = npix * s_n;
-            hipLaunchKernelGGL(wf_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, l.stream, c->view, f, (WfPath*)c->wf_paths,
-                               c->wf_queue[0], s_begin + s0, s_n);
-            int q = 0;
-            while (n > 0) {
-                /* [0] next queue index, [1] segments of this launch, [2] length of the next queue */
-                if (!hip_ok(hipMemsetAsync(c->wf_counters, 0, 3 * sizeof(unsigned long long), l.stream), "counter reset")) return RT1W_ERR_DEVICE;
-                hipLaunchKernelGGL(g_wf_trace[v], dim3(c->wf_grid[v]), dim3(RT_BLOCK), 0, l.stream, c->view, (WfPath*)c->wf_paths,
-                                   (const uint32_t*)c->wf_queue[q], n, c->wf_counters, refill);
-                hipLaunchKernelGGL(g_wf_shade[v], dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, l.stream, c->view,
-                                   (WfPath*)c->wf_paths, (const uint32_t*)c->wf_queue[q], n, c->wf_queue[q ^ 1], c->wf_counters,
-                                   c->wf_rad, (unsigned long long)s0 * npix);
-                if (!hip_ok(hipGetLastError(), "kernel launch") ||
-                    !hip_ok(hipMemcpyAsync(c->wf_hcounters, c->wf_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream), "counter copy") ||
-                    !hip_ok(hipStreamSynchronize(l.stream), "wavefront bounce")) return RT1W_ERR_DEVICE;
-                segments += c->wf_hcounters[1];
-                n = c->wf_hcounters[2];
-                q ^= 1;
+        for (uint32_t s0 = 0; s0 < s_cnt; s0 += s_pass) {
+            const uint32_t s_n = s_cnt - s0 < s_pass ? s_cnt - s0 : s_pass;
+            const unsigned long long n0 = npix * s_n;
+            hipLaunchKernelGGL(wf_init_counters, dim3(1), dim3(128), 0, l.stream, c->wf_counters, f.max_depth ? n0 : 0ull);
+            hipLaunchKernelGGL(wf_generate, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, l.stream, c->view, f, c->wf_q[0], s_begin + s0, s_n, c->wf_rad);
+            for (uint32_t b = 0; b < wf_bounces; ++b) {
+                hipLaunchKernelGGL(trace, dim3(grid_t), dim3(tblock), 0, l.stream, c->view, f, c->wf_q[b & 1u], c->wf_counters, b, s_begin + s0, c->wf_recs);
+                hipLaunchKernelGGL(shade, dim3(grid_s), dim3(RT_BLOCK), 0, l.stream, c->view, f, c->wf_q[b & 1u], c->wf_q[(b + 1u) & 1u], c->wf_counters, b,
+                                   s_begin + s0, c->wf_rad);
             }
+            /* whatever is still alive after the wavefront bounces runs to its end in one launch */
+            if (wf_bounces < f.max_depth)
+                hipLaunchKernelGGL(finish, dim3(c->wf_grid_finish[v - 2]), dim3(RT_BLOCK), 0, l.stream, c->view, f, c->wf_q[wf_bounces & 1u], c->wf_counters,
+                                   wf_bounces, s_begin + s0, c->wf_rad);
+            hipLaunchKernelGGL(wf_chunk_sum, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, l.stream, (const double*)c->wf_rad,
+                               l.d_partial + (size_t)ch * npix * 3, npix, s_n, s0 == 0u ? 1u : 0u);
         }
-        hipLaunchKernelGGL(wf_chunk_sum, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, l.stream, (const double*)c->wf_rad,
-                           l.d_partial + (size_t)ch * npix * 3, npix, s_cnt);
     }
     {
         unsigned int rb = 256;
@@ -523,13 +548,15 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
                            (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
     }
     (void)hipEventRecord(l.ev1, l.stream);
-    if (!hip_ok(hipGetLastError(), "kernel launch") || !hip_ok(hipStreamSynchronize(l.stream), "wavefront render")) return RT1W_ERR_DEVICE;
+    if (!hip_ok(hipGetLastError(), "kernel launch") ||
+        !hip_ok(hipMemcpyAsync(c->wf_hcounters + 1, &c->wf_counters->segs, sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream), "counter copy") ||
+        !hip_ok(hipStreamSynchronize(l.stream), "wavefront render")) return RT1W_ERR_DEVICE;
     if (stats) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, l.ev0, l.ev1);
-        stats->paths = npix * f.spp; stats->segments = segments; stats->kernel_ms = ms;
-        stats->chunk = f.chunk; stats->n_chunks = f.n_chunks; stats->grid = (uint32_t)c->wf_grid[v]; stats->block = RT_BLOCK;
-        stats->variant = (uint32_t)v; stats->sorted = 8u; /* bit 3: wavefront form */
+        stats->paths = npix * f.spp; stats->segments = c->wf_hcounters[1]; stats->kernel_ms = ms;
+        stats->chunk = f.chunk; stats->n_chunks = f.n_chunks; stats->grid = (uint32_t)grid_t; stats->block = (uint32_t)tblock;
+        stats->variant = (uint32_t)v; stats->sorted = 8u | (lds_recs ? 2u : 0u); /* bit 3: wavefront form; bit 1: walk records in LDS */
     }
     return RT1W_OK;
 }
@@ -641,7 +668,30 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->has_media = s->has_media; c->has_tex = s->has_tex; c->has_msphere = s->has_msphere;
     c->n_nodes = (uint32_t)s->flat_nodes.size();
     c->scope_depth = s->scope_depth;
+    c->stack_need = s->stack_need;
     c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth);
+    if (c->variant >= 2) {
+        /* walk records for the wavefront form: eligible when every MovingSphere has the same (time0, time1) */
+        std::vector<WfRec> recs(s->flat_nodes.size());
+        bool ok_ms = true, seen = false;
+        double t0 = 0.0, t1 = 1.0;
+        for (size_t i = 0; i < recs.size(); ++i) {
+            const RtNode& n = s->flat_nodes[i];
+            WfRec& r = recs[i];
+            r.kind = n.kind; r.b = n.b;
+            for (int k = 0; k < 6; ++k) r.d[k] = n.d[k];
+            r.d[6] = 0.0;
+            if ((n.kind & RT_KIND_MASK) == RT_MSPHERE) {
+                r.d[6] = n.e[2];
+                if (!seen) { t0 = n.e[0]; t1 = n.e[1]; seen = true; }
+                else if (memcmp(&t0, &n.e[0], 8) != 0 || memcmp(&t1, &n.e[1], 8) != 0) ok_ms = false;
+            }
+        }
+        if (ok_ms) {
+            if (!upload(&c->d_wf_recs, recs.data(), recs.size() * sizeof(WfRec))) { rt1w_context_destroy(c); return RT1W_ERR_DEVICE; }
+            c->wf_recs.p = (const WfRec*)c->d_wf_recs; c->wf_recs.ms_time0 = t0; c->wf_recs.ms_time1 = t1;
+        }
+    }
     if (rt1w::jit_eligible(*s)) {
         c->jit_src = rt1w::jit_source(*s);
         rt1w::JitInfo info;
@@ -655,7 +705,7 @@ void rt1w_context_destroy(rt1w_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images, c->d_out,
-                    c->wf_paths, c->wf_queue[0], c->wf_queue[1], c->wf_rad, c->wf_counters};
+                    c->wf_q[0].f, c->wf_q[0].u, c->wf_q[1].f, c->wf_q[1].u, c->wf_rad, c->wf_counters, c->d_wf_recs};
     if (c->wf_hcounters) (void)hipHostFree(c->wf_hcounters);
     for (void* b : bufs) if (b) (void)hipFree(b);
     lane_destroy(c->lane[0]);
