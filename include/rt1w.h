@@ -116,6 +116,24 @@ int rt1w_scene_build_reference(int arm, uint64_t build_seed, double aspect_ratio
                                const uint8_t* earth_rgb8, uint32_t earth_w, uint32_t earth_h,
                                rt1w_scene** out, uint32_t defaults[3]);
 
+/* OPT-IN traversal order of the BVHs.  Default RT1W_WALK_REFERENCE: every BVH node's children are visited
+ * left then right exactly as `BVHNode::hit` does (src/bvh.rs:38-47) -- the walk then tests the very primitives the reference
+ * tests, in its order, which is what makes the default results provably the reference's.  RT1W_WALK_NEAR_FAR visits the
+ * child on the ray's near side first (fewer node visits: the closest hit is found earlier and prunes the rest).  The
+ * closest hit does not depend on the order; what does is (a) which of two primitives hit at exactly the same t wins -- kept
+ * the reference's by preferring the larger pre-order index -- (b) the random numbers a ConstantMedium draws while being
+ * visited -- kept by leaving every node with a medium below it in the reference's order -- and (c) primitive tests the
+ * reference never runs because a box test with a fresher t_max pruned them: equal "almost surely" (a primitive hit outside
+ * its own bounding box by rounding would be needed) -- except for MovingSphere: the reference gives a scattered ray
+ * time = hit t (src/main.rs:86,145), which moves such a sphere far outside the box the BVH holds for it, so whether it is
+ * tested depends on the order.  RT1W_WALK_NEAR_FAR therefore also leaves subtrees with moving spheres in the reference's
+ * order; RT1W_WALK_NEAR_FAR_ALL reorders them too and is NOT result-preserving (measured on random_scene: 2 of 9600
+ * pixels differ at 4 spp).  Call on a committed scene, before creating contexts. */
+#define RT1W_WALK_REFERENCE 0u
+#define RT1W_WALK_NEAR_FAR 1u
+#define RT1W_WALK_NEAR_FAR_ALL 2u
+int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode);
+
 /* introspection of the committed flat scene (tests, DESIGN.md numbers) */
 typedef struct rt1w_scene_info {
     uint32_t n_nodes, n_lights, n_materials, n_textures, n_perlin;

@@ -115,6 +115,7 @@ _sig("rt1w_scene_set_camera", C.c_int, _P, _D3, _D3, _D3, C.c_double, C.c_double
 _sig("rt1w_scene_commit", C.c_int, _P)
 _sig("rt1w_scene_build_reference", C.c_int, C.c_int, C.c_uint64, C.c_double, _P, C.c_uint32, C.c_uint32,
      C.POINTER(_P), C.POINTER(C.c_uint32 * 3))
+_sig("rt1w_scene_set_walk_order", C.c_int, _P, C.c_uint32)
 _sig("rt1w_scene_get_info", C.c_int, _P, C.POINTER(SceneInfo))
 _sig("rt1w_scene_copy_flat", C.c_int64, _P, C.c_int, _P, C.c_uint64)
 _sig("rt1w_device_count", C.c_int)
@@ -289,6 +290,12 @@ class Scene:
                                        aperture, focus_dist, time0, time1))
 
     def commit(self): _ck(_lib.rt1w_scene_commit(self._h))
+
+    def set_walk_order(self, near_far):
+        """Opt-in traversal order (rt1w_scene_set_walk_order): False = the reference's left-then-right (default),
+        True = near child first in media-free subtrees.  On a committed scene, before creating contexts."""
+        _ck(_lib.rt1w_scene_set_walk_order(self._h, int(near_far)))   # 0 reference, 1 near-far (result-preserving), 2 near-far everywhere
+        return self
 
     def info(self):
         i = SceneInfo()

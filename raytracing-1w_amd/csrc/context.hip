@@ -238,9 +238,9 @@ struct rt1w_context {
     void* d_textures = nullptr; void* d_perlin = nullptr; void* d_images = nullptr;
     RtSceneView view{};
     double* d_out = nullptr; size_t out_bytes = 0;
-    int grid[RT_N_VARIANTS] = {0, 0, 0, 0};
-    int grid_sorted[RT_N_VARIANTS] = {0, 0, 0, 0};
-    int grid_cached[RT_N_VARIANTS] = {0, 0, 0, 0};
+    int grid[RT_N_VARIANTS] = {0, 0, 0, 0, 0};
+    int grid_sorted[RT_N_VARIANTS] = {0, 0, 0, 0, 0};
+    int grid_cached[RT_N_VARIANTS] = {0, 0, 0, 0, 0};
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
@@ -250,7 +250,7 @@ struct rt1w_context {
     WfCounters* wf_counters = nullptr; unsigned long long* wf_hcounters = nullptr;
     size_t wf_cap = 0;
     WfRecs wf_recs = {nullptr, 0.0, 1.0}; void* d_wf_recs = nullptr; /* walk records of the big scenes (null: not eligible) */
-    int wf_grid_trace[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wf_grid_shade[2] = {0, 0}, wf_grid_finish[2] = {0, 0};
+    int wf_grid_trace[18] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
     uint32_t stack_need = 0;
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
@@ -263,13 +263,13 @@ struct rt1w_context {
 
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
 static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV0>, rt_render_kernel<RtCfgV1>,
-                                                         rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>};
+                                                         rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>, rt_render_kernel<RtCfgV4>};
 /* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
  * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
-static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>};
+static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr};
 /* the reordering kernel exists for the variants where it pays (measured): the sweep variants */
 static render_kernel_t const g_kernels_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted<RtCfgV0>, rt_render_kernel_sorted<RtCfgV1>,
-                                                                nullptr, nullptr}; /* stack variants: measured 0.55x (LDS for stack + exchange halves occupancy) */
+                                                                nullptr, nullptr, nullptr}; /* stack variants: measured 0.55x (LDS for stack + exchange halves occupancy) */
 
 namespace {
 
@@ -448,13 +448,15 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
 typedef void (*wf_trace_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, WfRecs);
 typedef void (*wf_shade_t)(RtSceneView, RtFrame, WfQueue, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
 /* trace kernels: [variant 2/3][scene has wrappers][stack capacity 16/32] */
-static wf_trace_t const g_wf_trace[2][2][2] = {
+static wf_trace_t const g_wf_trace[3][2][2] = {
     {{wf_trace<RtCfgV2, false, 16>, wf_trace<RtCfgV2, false, 32>}, {wf_trace<RtCfgV2, true, 16>, wf_trace<RtCfgV2, true, 32>}},
-    {{wf_trace<RtCfgV3, false, 16>, wf_trace<RtCfgV3, false, 32>}, {wf_trace<RtCfgV3, true, 16>, wf_trace<RtCfgV3, true, 32>}}};
-static wf_trace_t const g_wf_trace_lds[2][2] = {{wf_trace_lds<RtCfgV2, false>, wf_trace_lds<RtCfgV2, true>}, {wf_trace_lds<RtCfgV3, false>, wf_trace_lds<RtCfgV3, true>}};
-static wf_shade_t const g_wf_shade[2] = {wf_shade<RtCfgV2>, wf_shade<RtCfgV3>};
+    {{wf_trace<RtCfgV3, false, 16>, wf_trace<RtCfgV3, false, 32>}, {wf_trace<RtCfgV3, true, 16>, wf_trace<RtCfgV3, true, 32>}},
+    {{wf_trace<RtCfgV4, false, 16>, wf_trace<RtCfgV4, false, 32>}, {wf_trace<RtCfgV4, true, 16>, wf_trace<RtCfgV4, true, 32>}}};
+static wf_trace_t const g_wf_trace_lds[3][2] = {{wf_trace_lds<RtCfgV2, false>, wf_trace_lds<RtCfgV2, true>}, {wf_trace_lds<RtCfgV3, false>, wf_trace_lds<RtCfgV3, true>},
+                                                {wf_trace_lds<RtCfgV4, false>, wf_trace_lds<RtCfgV4, true>}};
+static wf_shade_t const g_wf_shade[3] = {wf_shade<RtCfgV2>, wf_shade<RtCfgV3>, wf_shade<RtCfgV4>};
 typedef void (*wf_finish_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
-static wf_finish_t const g_wf_finish[2] = {wf_finish<RtCfgV2>, wf_finish<RtCfgV3>};
+static wf_finish_t const g_wf_finish[3] = {wf_finish<RtCfgV2>, wf_finish<RtCfgV3>, wf_finish<RtCfgV4>};
 #define RT_WF_PASS_PATHS (16ull << 20) /* paths in flight per pass: 2 queues x 16 Mi x 128 B = 4 GiB */
 
 /* the wavefront form of one render: per chunk of samples, passes of <= RT_WF_PASS_PATHS paths; per pass
@@ -498,7 +500,7 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
     const wf_trace_t trace = lds_recs ? g_wf_trace_lds[v - 2][c->scope_depth > 0u ? 1 : 0]
                                       : g_wf_trace[v - 2][c->scope_depth > 0u ? 1 : 0][c->stack_need <= 16u ? 0 : 1];
     const wf_shade_t shade = g_wf_shade[v - 2];
-    const int gi = lds_recs ? 8 + (v - 2) * 2 + (c->scope_depth > 0u ? 1 : 0) : (v - 2) * 4 + (c->scope_depth > 0u ? 2 : 0) + (c->stack_need <= 16u ? 0 : 1);
+    const int gi = lds_recs ? 12 + (v - 2) * 2 + (c->scope_depth > 0u ? 1 : 0) : (v - 2) * 4 + (c->scope_depth > 0u ? 2 : 0) + (c->stack_need <= 16u ? 0 : 1);
     if (!c->wf_grid_trace[gi] || !c->wf_grid_shade[v - 2]) {
         int per_cu = 0, per_cu_s = 0;
         hipDeviceProp_t prop;
@@ -669,7 +671,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->n_nodes = (uint32_t)s->flat_nodes.size();
     c->scope_depth = s->scope_depth;
     c->stack_need = s->stack_need;
-    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth);
+    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth, s->walk_order != 0u);
     if (c->variant >= 2) {
         /* walk records for the wavefront form: eligible when every MovingSphere has the same (time0, time1) */
         std::vector<WfRec> recs(s->flat_nodes.size());

@@ -434,15 +434,32 @@ RT_HD void rt_walk_exit(const RtSceneView& sc, RtWalk& k, uint32_t e) {
     if (k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
     else { k.cur = rt_ray_in_scope(nodes, k.scope, k.w); k.inv = rt_inv3(k.cur.d); }
 }
-template <bool EARLY, class Stack>
+template <class Cfg, bool EARLY, class Stack>
 RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
     bool hit;
     if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
     else hit = rt_aabb_hit_fast<EARLY>(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
     if (hit) {
-        if ((nd.kind & RT_KIND_MASK) == RT_BVH2) stk.push(nd.b);
-        stk.push(e + 1u); /* left child / only child: the next node in pre-order */
+        if ((nd.kind & RT_KIND_MASK) == RT_BVH2) {
+            uint32_t first = e + 1u, second = nd.b; /* left child = the next node in pre-order, then the right one: bvh.rs:38-47 */
+            const uint32_t ord = Cfg::ordered ? (nd.kind >> RT_BVH_ORDER_SHIFT) & RT_BVH_ORDER_MASK : 0u;
+            if (Cfg::ordered && ord != 0u) { /* opt-in near-far order (variant V4 only): the child on the ray's near side first */
+                const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
+                const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
+                if ((da < 0.0 && left_lower) || (da > 0.0 && !left_lower)) { first = nd.b; second = e + 1u; }
+            }
+            stk.push(second);
+            stk.push(first);
+        } else {
+            stk.push(e + 1u); /* only child: the next node in pre-order */
+        }
     }
+}
+/* Ties in t go to the primitive the reference tests LATER (bvh.rs:40, sphere.rs:43, aarect.rs:48: `t_max < root` keeps an
+ * equal root), i.e. to the larger pre-order index.  In the reference's own visiting order a later test always has the larger
+ * index, so this never rejects anything there; under the opt-in near-far order it is what keeps equal-t hits the reference's. */
+RT_HD bool rt_tie_ok(double t, uint32_t e, double best_t, uint32_t best_prim) {
+    return !(t == best_t && best_prim != RT_NONE && e < best_prim);
 }
 template <class Cfg>
 RT_HD void rt_walk_leaf(const RtSceneView& sc, RtWalk& k, uint32_t e, const RtNodeHot& nd) {
@@ -451,7 +468,7 @@ RT_HD void rt_walk_leaf(const RtSceneView& sc, RtWalk& k, uint32_t e, const RtNo
     bool hit;
     if (Cfg::msphere && kind == RT_MSPHERE) hit = rt_prim_t<Cfg>(sc.nodes[e], kind, k.cur.o, k.cur.d, k.time, k.t_min, k.best_t, t);
     else hit = rt_prim_hot_sel_t(nd, kind, k.cur.o, k.cur.d, k.t_min, k.best_t, t);
-    if (hit) { k.best_t = t; k.best_prim = e; k.best_scope = k.scope; }
+    if (hit && (!Cfg::ordered || rt_tie_ok(t, e, k.best_t, k.best_prim))) { k.best_t = t; k.best_prim = e; k.best_scope = k.scope; }
 }
 template <class Stack>
 RT_HD void rt_walk_wrap(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
@@ -486,7 +503,7 @@ RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& r
     const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
     const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
     RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
-    if (cls == RT_WK_BOX) rt_walk_box<Cfg::media>(k, e, nd, stk); /* media scenes: boundary walks run with few lanes */
+    if (cls == RT_WK_BOX) rt_walk_box<Cfg, Cfg::media>(k, e, nd, stk); /* media scenes: boundary walks run with few lanes */
     else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg>(sc, k, e, nd);
     else if (cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk);
     else rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);

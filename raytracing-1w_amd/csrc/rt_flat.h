@@ -32,6 +32,10 @@ enum {
     RT_DEFAULT = 11,  /* lights table only: a hittable without pdf_value/random overrides
                          (src/hittable.rs:66-71 defaults) */
     RT_KIND_MASK = 0xFF,
+    /* OPT-IN walk order (rt1w_scene_set_walk_order; all zero by default = the reference's left-then-right, bvh.rs:38-47):
+     * bits 9-10 of a BVH2 node = 1 + the axis along which its children are furthest apart, bit 11 = the left child is the
+     * lower one on that axis.  The stack walk then visits the child on the ray's near side first. */
+    RT_BVH_ORDER_SHIFT = 9, RT_BVH_ORDER_MASK = 3, RT_BVH_LEFT_LOWER = 0x800,
     RT_LEAF_FLIPPED = 0x100 /* leaf wrapped directly by FlipFace (hittable.rs:286-292): the flattener folds the
                                wrapper into this flag; the flip is applied right after the leaf's own record,
                                i.e. exactly where the innermost wrapper's fix-up would run */
@@ -158,8 +162,9 @@ RT_HD uint32_t rt_frame_row(const RtFrame& f, uint32_t py) {
 /* compile-time feature set of a kernel variant: code for absent features is not
  * generated, which is what keeps the register budget of the simple scenes low */
 /* `Topo_`: void, or a type with the scene's node kinds and subtree ends as compile-time arrays (rt_sweep_static) */
-template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_, int SCOPE_DEPTH_ = 3, class Topo_ = void>
+template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_, int SCOPE_DEPTH_ = 3, class Topo_ = void, bool ORDERED_ = false>
 struct RtCfg {
+    static constexpr bool ordered = ORDERED_; /* stack walk honours the opt-in near-far bits of BVH2 nodes (rt1w_scene_set_walk_order) */
     typedef Topo_ Topo;
     static constexpr int scope_depth = SCOPE_DEPTH_; /* deepest wrapper nesting the sweep variant handles */
     static constexpr bool media = MEDIA_;     /* scene contains ConstantMedium nodes */
@@ -172,10 +177,12 @@ typedef RtCfg<false, false, false, true, 2> RtCfgV0; /* small scene, solid colou
 typedef RtCfg<true, true, true, true> RtCfgV1;    /* small scene, every feature */
 typedef RtCfg<false, true, true, false> RtCfgV2;  /* large scene without media (random_scene) */
 typedef RtCfg<true, true, true, false> RtCfgV3;   /* large scene, every feature (final_scene) */
-#define RT_N_VARIANTS 4
+typedef RtCfg<true, true, true, false, 3, void, true> RtCfgV4; /* V3 + the opt-in near-far walk order (only scenes that asked for it) */
+#define RT_N_VARIANTS 5
 /* cheapest valid variant for a scene; `force` >= 0 overrides when valid */
-inline int rt_pick_variant(uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth) {
+inline int rt_pick_variant(uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth, bool ordered = false) {
     if (n_nodes <= RT_SWEEP_MAX_NODES) return (!media && !tex && !msphere && scope_depth <= 2u) ? 0 : 1;
+    if (ordered) return 4;
     return media ? 3 : 2;
 }
 inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth) {
@@ -185,6 +192,7 @@ inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool
         case 1: return true;
         case 2: return !media;
         case 3: return true;
+        case 4: return true; /* reference order unless the scene's nodes carry order bits */
         default: return false;
     }
 }

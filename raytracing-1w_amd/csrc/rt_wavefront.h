@@ -269,15 +269,25 @@ __device__ __forceinline__ void wf_trace_body(const RtSceneView& sc, const RtFra
                 if (RT_WAVE_ANY(rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
                 else hit = rt_aabb_hit_fast<false>(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
                 if (hit) {
-                    if ((nd.kind & RT_KIND_MASK) == RT_BVH2) stk.push(nd.b);
-                    e = e + 1u;
+                    uint32_t first = e + 1u;
+                    if ((nd.kind & RT_KIND_MASK) == RT_BVH2) {
+                        uint32_t second = nd.b;
+                        const uint32_t ord = Cfg::ordered ? (nd.kind >> RT_BVH_ORDER_SHIFT) & RT_BVH_ORDER_MASK : 0u; /* opt-in near-far order, as rt_walk_box */
+                        if (Cfg::ordered && ord != 0u) {
+                            const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
+                            const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
+                            if ((da < 0.0 && left_lower) || (da > 0.0 && !left_lower)) { first = nd.b; second = e + 1u; }
+                        }
+                        stk.push(second);
+                    }
+                    e = first;
                     do_pop = false;
                 }
             }
         } else if (pick == WF_K_SPHERE) {
             if (act) {
                 double t;
-                if (rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], k.cur.o, k.cur.d, k.t_min, k.best_t, t)) {
+                if (rt_sphere_root(rt_v3(nd.d[0], nd.d[1], nd.d[2]), nd.d[3], k.cur.o, k.cur.d, k.t_min, k.best_t, t) && (!Cfg::ordered || rt_tie_ok(t, e, k.best_t, k.best_prim))) {
                     k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
                 }
             }
@@ -288,7 +298,7 @@ __device__ __forceinline__ void wf_trace_body(const RtSceneView& sc, const RtFra
                     const RtV3 c0 = rt_v3(nd.d[0], nd.d[1], nd.d[2]), c1 = rt_v3(nd.d[3], nd.d[4], nd.d[5]);
                     const RtV3 center = c0 + ms_frac * (c1 - c0);
                     double t;
-                    if (rt_sphere_root(center, nd.d[6], k.cur.o, k.cur.d, k.t_min, k.best_t, t)) {
+                    if (rt_sphere_root(center, nd.d[6], k.cur.o, k.cur.d, k.t_min, k.best_t, t) && (!Cfg::ordered || rt_tie_ok(t, e, k.best_t, k.best_prim))) {
                         k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
                     }
                 }
@@ -296,7 +306,7 @@ __device__ __forceinline__ void wf_trace_body(const RtSceneView& sc, const RtFra
         } else if (pick == WF_K_RECT) {
             if (act) {
                 double t;
-                if (wf_rect_t(nd, nd.kind & RT_KIND_MASK, k.cur.o, k.cur.d, k.t_min, k.best_t, t)) {
+                if (wf_rect_t(nd, nd.kind & RT_KIND_MASK, k.cur.o, k.cur.d, k.t_min, k.best_t, t) && (!Cfg::ordered || rt_tie_ok(t, e, k.best_t, k.best_prim))) {
                     k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
                 }
             }

@@ -632,6 +632,59 @@ int rt1w_scene_commit(rt1w_scene* s) {
     return RT1W_OK;
 }
 
+/* ---- opt-in walk order ------------------------------------------------- */
+namespace {
+/* rough centre of a flat subtree in its parent's space: only used to pick which child is "near" */
+RtV3 subtree_centre(const std::vector<RtNode>& N, uint32_t i) {
+    const RtNode& n = N[i];
+    switch (n.kind & RT_KIND_MASK) {
+        case RT_BVH2: case RT_BVH1: return rt_v3(0.5 * (n.d[0] + n.d[3]), 0.5 * (n.d[1] + n.d[4]), 0.5 * (n.d[2] + n.d[5]));
+        case RT_SPHERE: return rt_v3(n.d[0], n.d[1], n.d[2]);
+        case RT_MSPHERE: return rt_v3(0.5 * (n.d[0] + n.d[3]), 0.5 * (n.d[1] + n.d[4]), 0.5 * (n.d[2] + n.d[5]));
+        case RT_XY: return rt_v3(0.5 * (n.d[0] + n.d[1]), 0.5 * (n.d[2] + n.d[3]), n.d[4]);
+        case RT_XZ: return rt_v3(0.5 * (n.d[0] + n.d[1]), n.d[4], 0.5 * (n.d[2] + n.d[3]));
+        case RT_YZ: return rt_v3(n.d[4], 0.5 * (n.d[0] + n.d[1]), 0.5 * (n.d[2] + n.d[3]));
+        case RT_TRANSLATE: { RtV3 c = subtree_centre(N, n.a); return rt_v3(c.x + n.d[0], c.y + n.d[1], c.z + n.d[2]); }
+        case RT_ROTATE_Y: { RtV3 c = subtree_centre(N, n.a); return rt_v3(n.d[1] * c.x + n.d[0] * c.z, c.y, -n.d[0] * c.x + n.d[1] * c.z); }
+        default: return subtree_centre(N, n.a); /* FlipFace, ConstantMedium: the child's */
+    }
+}
+bool subtree_has(const std::vector<RtNode>& N, uint32_t i, uint32_t kind) {
+    for (uint32_t j = i; j < N[i].skip; ++j) if ((N[j].kind & RT_KIND_MASK) == kind) return true;
+    return false;
+}
+} // namespace
+
+int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode) {
+    if (!s) { set_error("null scene"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
+    if (mode > RT1W_WALK_NEAR_FAR_ALL) { set_error("unknown walk order"); return RT1W_ERR_INVALID; }
+    std::vector<RtNode>& N = s->flat_nodes;
+    const uint32_t clear = ~((uint32_t)(RT_BVH_ORDER_MASK << RT_BVH_ORDER_SHIFT) | (uint32_t)RT_BVH_LEFT_LOWER);
+    for (uint32_t i = 0; i < N.size(); ++i) {
+        if ((N[i].kind & RT_KIND_MASK) != RT_BVH2) continue;
+        N[i].kind &= clear;
+        /* a ConstantMedium draws a random number while it is visited (constant_medium.rs:85), with the closest hit so far as
+         * its t_max: nodes with a medium below them keep the reference's order, so every medium is reached with the same
+         * closest hit and the random stream is consumed identically */
+        if (mode == RT1W_WALK_REFERENCE || subtree_has(N, i, RT_MEDIUM)) continue;
+        /* a scattered ray carries time = hit t (main.rs:86,145), so MovingSphere::center extrapolates the sphere far outside
+         * the bounding box the BVH holds for it (moving_sphere.rs:23-26,72-84): whether such a sphere is tested at all depends on
+         * which boxes were pruned before -- on the order.  Measured on random_scene: 2 of 9600 pixels differ.  So the
+         * result-preserving mode leaves subtrees with moving spheres alone too; RT1W_WALK_NEAR_FAR_ALL does not */
+        if (mode == RT1W_WALK_NEAR_FAR && subtree_has(N, i, RT_MSPHERE)) continue;
+        const RtV3 l = subtree_centre(N, N[i].a), r = subtree_centre(N, N[i].b);
+        const double dx = rt_abs(l.x - r.x), dy = rt_abs(l.y - r.y), dz = rt_abs(l.z - r.z);
+        uint32_t axis = dx >= dy ? (dx >= dz ? 0u : 2u) : (dy >= dz ? 1u : 2u);
+        const double la = rt_get(l, (int)axis), ra = rt_get(r, (int)axis);
+        if (!(la < ra) && !(la > ra)) continue; /* coincident (or NaN): nothing to order by */
+        N[i].kind |= (axis + 1u) << RT_BVH_ORDER_SHIFT;
+        if (la < ra) N[i].kind |= RT_BVH_LEFT_LOWER;
+    }
+    s->walk_order = mode;
+    return RT1W_OK;
+}
+
 int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
     if (!s || !out) { set_error("null argument"); return RT1W_ERR_INVALID; }
     if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
@@ -645,7 +698,7 @@ int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
     out->has_media = s->has_media ? 1u : 0u;
     out->has_textures = s->has_tex ? 1u : 0u;
     out->has_moving = s->has_msphere ? 1u : 0u;
-    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere, s->scope_depth);
+    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere, s->scope_depth, s->walk_order != 0u);
     out->bytes = s->flat_nodes.size() * sizeof(RtNode) + s->flat_lights.size() * sizeof(RtNode) +
                  s->materials.size() * sizeof(RtMaterial) + s->textures.size() * sizeof(RtTexture) +
                  s->perlin.size() * sizeof(RtPerlin) + s->images.size();

@@ -55,6 +55,7 @@ struct rt1w_scene {
     uint32_t flat_root = RT_NONE;
     uint32_t stack_need = 0, scope_depth = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
+    uint32_t walk_order = 0; /* RT1W_WALK_* */
 };
 
 #endif
