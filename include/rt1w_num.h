@@ -116,18 +116,68 @@ struct RtRng {
 #define RT_RNG_ASSERT(c) ((void)0)
 #endif
 
+#if defined(RT_RNG_REFSTREAM)
+/* REFERENCE-STREAM BUILD (kernels of csrc/context_ref.hip and oracle/liborc_flat_ref.so only; selected per render with
+ * RT1W_RNG_REFERENCE): the word stream is the reference's own `StdRng::seed_from_u64(j * image_width + i)` (src/main.rs:964,
+ * `type MyRng = StdRng`, main.rs:2) = ChaCha12 keyed by the PCG32 expansion of the pixel seed (rand 0.8.4, rand_chacha 0.3.1,
+ * rand_core 0.6.3 -- un-vendored crates, published algorithms restated; pinned by oracle/refstream.h's known answers and by
+ * the reference's own PNG), ONE stream per pixel drawn on through all of its samples.  Group `blk` of four words is
+ * words 4*(blk & 3).. of ChaCha block blk >> 2 (the 64-word buffer of rand_chacha is just four consecutive blocks); the
+ * block is recomputed for each group -- four times the arithmetic, no indexed buffer, and the state stays the RtRng the
+ * kernels already carry (k0,k1 = the pixel seed). */
+RT_HD uint32_t rt_rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+RT_HD void rt_rng_gen_b(RtRng& r) {
+    /* rand_core SeedableRng::seed_from_u64: eight PCG32 (XSH RR) outputs, state advanced first */
+    uint64_t st = ((uint64_t)r.k1 << 32) | r.k0;
+    uint32_t key[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        st = st * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xs = (uint32_t)(((st >> 18) ^ st) >> 27);
+        const uint32_t rot = (uint32_t)(st >> 59);
+        key[i] = (xs >> rot) | (xs << ((32u - rot) & 31u));
+    }
+    const uint32_t ctr = r.blk >> 2; /* 64-bit block counter in the reference; 2^34 words per pixel are out of reach here */
+    uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+    uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+    uint32_t x12 = ctr, x13 = 0u, x14 = 0u, x15 = 0u;
+#define RT_QR(a, b, c, d) a += b; d ^= a; d = rt_rotl32(d, 16); c += d; b ^= c; b = rt_rotl32(b, 12); a += b; d ^= a; d = rt_rotl32(d, 8); c += d; b ^= c; b = rt_rotl32(b, 7);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { /* ChaCha12: six double rounds */
+        RT_QR(x0, x4, x8, x12) RT_QR(x1, x5, x9, x13) RT_QR(x2, x6, x10, x14) RT_QR(x3, x7, x11, x15)
+        RT_QR(x0, x5, x10, x15) RT_QR(x1, x6, x11, x12) RT_QR(x2, x7, x8, x13) RT_QR(x3, x4, x9, x14)
+    }
+#undef RT_QR
+    x0 += 0x61707865u; x1 += 0x3320646eu; x2 += 0x79622d32u; x3 += 0x6b206574u;
+    x4 += key[0]; x5 += key[1]; x6 += key[2]; x7 += key[3]; x8 += key[4]; x9 += key[5]; x10 += key[6]; x11 += key[7];
+    x12 += ctr;
+    const uint32_t g = r.blk & 3u;
+    r.b0 = g == 0u ? x0 : (g == 1u ? x4 : (g == 2u ? x8 : x12));
+    r.b1 = g == 0u ? x1 : (g == 1u ? x5 : (g == 2u ? x9 : x13));
+    r.b2 = g == 0u ? x2 : (g == 1u ? x6 : (g == 2u ? x10 : x14));
+    r.b3 = g == 0u ? x3 : (g == 1u ? x7 : (g == 2u ? x11 : x15));
+    r.blk += 1u; r.bv = 1u;
+}
+#else
 RT_HD void rt_rng_gen_b(RtRng& r) {
     RtPhiloxOut o = rt_philox4x32_10(r.blk, r.c1, r.c2, r.c3, r.k0, r.k1);
     r.b0 = o.w0; r.b1 = o.w1; r.b2 = o.w2; r.b3 = o.w3;
     r.blk += 1u; r.bv = 1u;
 }
+#endif
 /* make sure the next n words can be taken without generating (n <= 4 + left) */
 RT_HD void rt_rng_reserve(RtRng& r, uint32_t n) {
     if (r.left + (r.bv << 2) < n) rt_rng_gen_b(r);
 }
 /* words a 64-bit draw (resp. two of them) may consume, counting the alignment skip */
+#if defined(RT_RNG_REFSTREAM)
+/* rand_core BlockRng::next_u64: two consecutive words at the current index, no alignment */
+RT_HD uint32_t rt_rng_need_u64(const RtRng&) { return 2u; }
+RT_HD uint32_t rt_rng_need_2u64(const RtRng&) { return 4u; }
+#else
 RT_HD uint32_t rt_rng_need_u64(const RtRng& r) { return 2u + (r.left & 1u); }
 RT_HD uint32_t rt_rng_need_2u64(const RtRng& r) { return 4u + (r.left & 1u); }
+#endif
 /* top up B unconditionally */
 RT_HD void rt_rng_fill(RtRng& r) { if (!r.bv) rt_rng_gen_b(r); }
 
@@ -162,6 +212,13 @@ RT_HD uint32_t rt_take_u32(RtRng& r) {
     r.left -= 1u;
     return w;
 }
+#if defined(RT_RNG_REFSTREAM)
+RT_HD uint64_t rt_take_u64(RtRng& r) { /* low word first, wherever the index stands (may cross into the next group) */
+    const uint64_t lo = rt_take_u32(r);
+    const uint64_t hi = rt_take_u32(r);
+    return (hi << 32) | lo;
+}
+#else
 RT_HD uint64_t rt_take_u64(RtRng& r) {
     if (r.left & 1u) { r.a0 = r.a1; r.a1 = r.a2; r.a2 = r.a3; r.left -= 1u; } /* even-align */
     if (r.left == 0u) rt_rng_pull(r);
@@ -170,6 +227,7 @@ RT_HD uint64_t rt_take_u64(RtRng& r) {
     r.left -= 2u;
     return v;
 }
+#endif
 /* ---- checked draws (reserve + take): what the host code and the literal oracle use ---- */
 RT_HD uint32_t rt_next_u32(RtRng& r) { rt_rng_reserve(r, 1u); return rt_take_u32(r); }
 RT_HD uint64_t rt_next_u64(RtRng& r) { rt_rng_reserve(r, rt_rng_need_u64(r)); return rt_take_u64(r); }

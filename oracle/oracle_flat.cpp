@@ -42,8 +42,8 @@ struct HostStack {
 
 template <class Cfg>
 static void run_path(const RtSceneView& sc, const RtFrame& f, uint32_t px, uint32_t py, uint32_t s, HostStack& stk,
-                     RtV3& sum, uint64_t& segs) {
-    RtPath path;
+                     RtV3& sum, uint64_t& segs, RtPath& path) { /* `path` lives as long as the pixel: the reference-stream build
+                                                                   (-DRT_RNG_REFSTREAM) draws all samples of a pixel from one stream */
     rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
     while (path.alive) {
         segs += path.depth_left != 0u ? 1u : 0u;
@@ -85,20 +85,21 @@ int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint
             if (p >= npix) break;
             uint32_t px = (uint32_t)(p % f.tile_w), py = (uint32_t)(p / f.tile_w);
             RtV3 total = rt_v3(0.0, 0.0, 0.0);
+            RtPath path;
             for (uint32_t c = 0; c < f.n_chunks; ++c) {
                 uint32_t s = c * f.chunk;
                 uint32_t s_end = s + f.chunk < f.spp ? s + f.chunk : f.spp;
                 RtV3 sum = rt_v3(0.0, 0.0, 0.0);
                 for (; s < s_end; ++s) {
                     switch (variant) { /* the same feature-specialised variants the GPU library builds */
-                        case 0: run_path<RtCfgV0>(sc, f, px, py, s, stk, sum, segs); break;
-                        case 1: run_path<RtCfgV1>(sc, f, px, py, s, stk, sum, segs); break;
-                        case 2: run_path<RtCfgV2>(sc, f, px, py, s, stk, sum, segs); break;
-                        case 4: run_path<RtCfgV4>(sc, f, px, py, s, stk, sum, segs); break;
+                        case 0: run_path<RtCfgV0>(sc, f, px, py, s, stk, sum, segs, path); break;
+                        case 1: run_path<RtCfgV1>(sc, f, px, py, s, stk, sum, segs, path); break;
+                        case 2: run_path<RtCfgV2>(sc, f, px, py, s, stk, sum, segs, path); break;
+                        case 4: run_path<RtCfgV4>(sc, f, px, py, s, stk, sum, segs, path); break;
 #ifdef ORC_STATIC_CASES
                         ORC_STATIC_CASES
 #endif
-                        default: run_path<RtCfgV3>(sc, f, px, py, s, stk, sum, segs); break;
+                        default: run_path<RtCfgV3>(sc, f, px, py, s, stk, sum, segs, path); break;
                     }
                 }
                 total = total + sum;
@@ -121,6 +122,14 @@ int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint
     return bad.load() ? -2 : 0;
 }
 
+/* 1: built with -DRT_RNG_REFSTREAM (the reference's ChaCha12 stream per pixel; include/rt1w_num.h) */
+int orcflat_is_refstream(void) {
+#ifdef RT_RNG_REFSTREAM
+    return 1;
+#else
+    return 0;
+#endif
+}
 /* number of compile-time topologies built in as variants 100.. (0 in the ordinary build) */
 int orcflat_n_static(void) {
 #ifdef ORC_N_STATIC

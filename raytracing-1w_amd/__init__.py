@@ -37,6 +37,7 @@ UNSORTED = 2
 LDS_NODES = 4
 GENERIC = 8  # do not use a scene-specialised kernel for this render
 OUT_FRAME = 32  # rt1w_render: `out` is the whole image; only the tile's pixels are written, at their image positions
+RNG_REFERENCE = 64  # parity mode: the reference's own ChaCha12 stream per pixel (main.rs:964)
 WAVEFRONT = 16  # big scenes: path state queued in HBM, trace / shade kernels per bounce
 SPECIALISE_CACHED_ONLY = 1
 
@@ -336,9 +337,9 @@ class Context:
 
     @staticmethod
     def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False,
-                strips=None, out_frame=False):
+                strips=None, out_frame=False, reference_stream=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (((variant + 1) << 8) if variant is not None else 0)
         sr, sp = strips if strips is not None else (0, 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp)
 
@@ -358,13 +359,14 @@ class Context:
         return rc == 0 and bool(info.active)
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
-               variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False, strips=None, out=None, frame=None):
+               variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False, strips=None, out=None, frame=None,
+               reference_stream=False):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict).
         strips=(strip_rows, strip_period): row-interleaved tile (tile row r = image row y0 + r//strip_rows*strip_period +
         r%strip_rows).  out: caller's array for the packed tile (e.g. pinned_empty).  frame: caller's WHOLE image
         [height, width, 3]; the tile's pixels are written at their image positions (RT1W_OUT_FRAME) and `frame` is returned."""
         p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront,
-                         strips, frame is not None)
+                         strips, frame is not None, reference_stream)
         if frame is not None:
             assert frame.dtype == np.float64 and frame.shape == (height, width, 3) and frame.flags.c_contiguous
             out = frame
@@ -376,9 +378,9 @@ class Context:
         _ck(_lib.rt1w_render(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
-    def render_u8(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0):
+    def render_u8(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, reference_stream=False):
         """Quantised on the device, rows top-down as the reference prints them: uint8 [tile_h, tile_w, 3]."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, False)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, False, reference_stream=reference_stream)
         out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.uint8)
         st = Stats()
         _ck(_lib.rt1w_render_u8(self._h, C.byref(p), out.ctypes.data_as(_P), C.byref(st)))

@@ -28,120 +28,23 @@
 #include <vector>
 
 #include "rt1w.h"
-#include "rt_kernel_sorted.h"
+#include "rt_kernel_plain.h"
 #include "rt_wavefront.h"
 #include "scene.h"
 #include "jit.h"
 
+/* context_ref.hip: the plain kernels built with the reference's own random stream (RT1W_RNG_REFERENCE) */
+extern "C" int rt1w_internal_ref_blocks_per_cu(int stack_walk);
+extern "C" int rt1w_internal_ref_launch(int stack_walk, const void* view, const void* frame, double* partial, unsigned long long* counters,
+                                        int grid, hipStream_t stream);
+extern "C" unsigned rt1w_internal_ref_sizeof(int what);
+
 namespace {
 
-/* 16-bit entries (node index < 32768, wrapper-exit flag in bit 15): half the LDS, used together with
- * the LDS node cache */
-struct LdsStack16 {
-    uint16_t* base;
-    int sp;
-    __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); ++sp; }
-    __device__ __forceinline__ uint32_t pop() { --sp; uint32_t x = base[sp * RT_BLOCK]; return (x & 0x7FFFu) | ((x & 0x8000u) ? RT_POP_FLAG : 0u); }
-};
-/* hot halves of all nodes copied into LDS once per workgroup (scenes of <= RT_LDS_NODE_CAP nodes): the
- * stack walk's dependent node fetches then cost LDS latency instead of L2/HBM latency */
-#define RT_LDS_NODE_CAP 1024
-struct LdsNodes {
-    const RtNodeHot* base;
-    __device__ __forceinline__ RtNodeHot hot(uint32_t n) const { return base[n]; }
-};
-
-/* counters[0] = next work item, counters[1] = traced segments */
-#ifndef RT_SWEEP_WAVES
-#define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
-#endif
 template <class Cfg, bool CACHE = false>
-__global__ __launch_bounds__(RT_BLOCK, Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : (Cfg::sweep || CACHE ? 2 : 3)) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
-                                                            unsigned long long* __restrict__ counters) {
-    /* the sweep variants need no traversal stack (and no LDS at all) */
-    typedef typename std::conditional<CACHE, uint16_t, uint32_t>::type stack_word;
-    __shared__ stack_word stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
-    __shared__ RtNodeHot node_cache[CACHE ? RT_LDS_NODE_CAP : 1];
-    typename std::conditional<CACHE, LdsStack16, LdsStack>::type stk;
-    stk.base = stack_mem + threadIdx.x;
-    stk.sp = 0;
-    typename std::conditional<CACHE, LdsNodes, RtGlobalNodes>::type ns;
-    if constexpr (CACHE) {
-        /* cooperative copy: 16 bytes per lane per step */
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
-        uint4* dst = reinterpret_cast<uint4*>(node_cache);
-        for (uint32_t i = threadIdx.x; i < sc.n_nodes * 4u; i += RT_BLOCK) dst[i] = src[(i >> 2) * 6u + (i & 3u)]; /* 96-B records, first 64 B */
-        __syncthreads();
-        ns.base = node_cache;
-    } else {
-        ns.p = sc.nodes;
-    }
-
-#ifdef RT_STAMPS
-    if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 16; ++k) rt_stamp_acc[threadIdx.x >> 6][k] = 0;
-        rt_stamp_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    const unsigned long long n_items = rt_item_count(f);
-    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
-    unsigned long long item = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-    bool fresh = true; /* `item` holds an id that was not decoded yet */
-    bool have = false;
-    uint32_t px = 0, py = 0, chunk = 0, s = 0, s_end = 0;
-    RtV3 sum = rt_v3(0.0, 0.0, 0.0);
-    RtPath path;
-    path.alive = false;
-    unsigned long long segs = 0;
-
-    for (;;) {
-        RT_STAMP(0);
-        if (!path.alive) {
-            if (have && s == s_end) {
-                double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
-                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
-                have = false;
-            }
-            while (!have) {
-                if (!fresh) {
-                    /* wave-aggregated fetch: the lanes that need an item share one atomic */
-                    unsigned long long need = __ballot(1);
-                    uint32_t cnt = (uint32_t)__popcll(need);
-                    uint32_t rank = lane_prefix(need);
-                    unsigned long long base_item = 0;
-                    if (rank == 0u) base_item = atomicAdd(&counters[0], (unsigned long long)cnt);
-                    /* rank 0 is the first active lane: broadcast its value */
-                    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_item);
-                    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_item >> 32));
-                    item = (((unsigned long long)hi << 32) | lo) + rank;
-                }
-                fresh = false;
-                if (item >= n_items) break;
-                rt_item_decode(f, item, px, py, chunk);
-                if (px < f.tile_w && py < f.tile_h) {
-                    s = chunk * f.chunk;
-                    s_end = s + f.chunk < f.spp ? s + f.chunk : f.spp;
-                    sum = rt_v3(0.0, 0.0, 0.0);
-                    have = true;
-                }
-            }
-            if (!have) break; /* no work left: this lane retires */
-            rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
-            RT_STAMP(1);
-        }
-        segs += path.depth_left != 0u ? 1ull : 0ull;
-        rt_path_step<Cfg>(sc, ns, path, stk);
-        if (!path.alive) {
-            sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
-            ++s;
-        }
-        RT_STAMP(6);
-    }
-    if (segs) atomicAdd(&counters[1], segs);
-#ifdef RT_STAMPS
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 16; ++k) atomicAdd(&g_stamp_total[k], rt_stamp_acc[threadIdx.x >> 6][k]);
-#endif
+__global__ __launch_bounds__(RT_BLOCK, RT_PLAIN_WAVES(Cfg, CACHE)) void rt_render_kernel(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+                                                                                  unsigned long long* __restrict__ counters) {
+    rt_render_plain_body<Cfg, CACHE>(sc, f, partial, counters);
 }
 
 /* the reordering kernel proper (rt_kernel_sorted.h) */
@@ -252,6 +155,7 @@ struct rt1w_context {
     WfRecs wf_recs = {nullptr, 0.0, 1.0}; void* d_wf_recs = nullptr; /* walk records of the big scenes (null: not eligible) */
     int wf_grid_trace[18] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
     uint32_t stack_need = 0;
+    int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
     hipModule_t jit_mod = nullptr;
@@ -325,7 +229,7 @@ void lane_destroy(RtLane& l) {
     l = RtLane();
 }
 
-struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit; };
+struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref; };
 
 /* what the launch will need, without launching: frame, variant, launch shape */
 int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
@@ -339,6 +243,21 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     if (f.chunk > f.spp) f.chunk = f.spp;
     f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
     L.npix = (unsigned long long)f.tile_w * f.tile_h;
+    L.ref = false;
+    if (p->flags & RT1W_RNG_REFERENCE) {
+        /* the reference's own stream: one lane owns a pixel for all its samples (main.rs:964-989) */
+        if (p->sample_offset != 0u) { rt1w::set_error("RT1W_RNG_REFERENCE: one stream per pixel, sample_offset must be 0"); return RT1W_ERR_INVALID; }
+        f.chunk = f.spp; f.n_chunks = 1u; f.global_seed = 0u;
+        const bool stack_walk = c->n_nodes > RT_SWEEP_MAX_NODES;
+        if (!c->ref_grid[stack_walk]) {
+            hipDeviceProp_t prop;
+            if (!hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
+            c->ref_grid[stack_walk] = prop.multiProcessorCount * rt1w_internal_ref_blocks_per_cu(stack_walk ? 1 : 0);
+        }
+        L.ref = true; L.jit = false; L.sorted = false; L.cached = false;
+        L.variant = stack_walk ? 3 : 1; L.grid = c->ref_grid[stack_walk]; L.block = RT_BLOCK;
+        return RT1W_OK;
+    }
     int variant = c->variant;
     if (p->flags >> 8) {
         variant = (int)((p->flags >> 8) & 0xFFu) - 1;
@@ -371,7 +290,12 @@ int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
 int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const RtLaunch& L, double* d_out) {
     hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block);
     (void)hipEventRecord(l.ev0, l.stream);
-    if (L.jit) {
+    if (L.ref) {
+        if (rt1w_internal_ref_sizeof(0) != sizeof(RtSceneView) || rt1w_internal_ref_sizeof(1) != sizeof(RtFrame) ||
+            rt1w_internal_ref_launch(L.variant == 3 ? 1 : 0, &c->view, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
+            rt1w::set_error("reference-stream kernel launch failed"); return RT1W_ERR_DEVICE;
+        }
+    } else if (L.jit) {
         RtSceneView view = c->view;
         RtFrame frame = L.f;
         double* partial = l.d_partial;
@@ -405,7 +329,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u);
     }
     return RT1W_OK;
 }
@@ -578,7 +502,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
     if (rc < 0) return rc;
     RtLane& l = c->lane[0];
     if ((rc = lane_reserve_partial(l, L)) < 0) return rc;
-    if ((p->flags & RT1W_WAVEFRONT) && !L.jit && !L.sorted) return render_wavefront(c, p, L, d_out, stats);
+    if ((p->flags & RT1W_WAVEFRONT) && !L.jit && !L.sorted && !L.ref) return render_wavefront(c, p, L, d_out, stats);
     if ((rc = render_launch(c, l, p, L, d_out)) < 0) return rc;
     return render_finish(l, L, stats);
 }

@@ -914,7 +914,13 @@ RT_HD double rt_reflectance(double cosine, double ref_idx) {                  /*
 /* main.rs:964-971 + Camera::get_ray camera.rs:61-73 */
 RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, uint32_t j,
                          uint32_t sample, RtPath& p) {
+#if defined(RT_RNG_REFSTREAM)
+    /* main.rs:964-967: the pixel's stream is seeded once, before its sample loop, and every sample draws on from where
+     * the previous one stopped (a lane runs all samples of its pixel in order: chunk = spp, sample_offset = 0) */
+    if (sample == 0u) p.rng = rt_rng_make((uint32_t)((uint64_t)j * f.width + i), (uint32_t)(((uint64_t)j * f.width + i) >> 32), 0u, 0u, 0u);
+#else
     p.rng = rt_rng_pixel_sample((uint64_t)j * f.width + i, sample, f.global_seed);
+#endif
     rt_rng_reserve(p.rng, 4u);
     double u = ((double)i + rt_take_f64(p.rng)) / (double)(f.width - 1u);
     double v = ((double)j + rt_take_f64(p.rng)) / (double)(f.height - 1u);

@@ -13,7 +13,7 @@ _P = C.c_void_p
 
 
 def _build():
-    need = [os.path.join(ORACLE_DIR, n) for n in ("liborc_rt1w.so", "liborc_flat.so", "liborc_ref.so")]
+    need = [os.path.join(ORACLE_DIR, n) for n in ("liborc_rt1w.so", "liborc_flat.so", "liborc_ref.so", "liborc_flat_ref.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
@@ -135,6 +135,13 @@ B.orcflat_sizeof.restype = C.c_uint32
 B.orcflat_item_count.restype = C.c_uint64
 B.orcflat_item_count.argtypes = [C.POINTER(Frame)]
 B.orcflat_item_decode.argtypes = [C.POINTER(Frame), C.c_uint64, _P]
+
+
+def flat_ref_lib():
+    """CPU build of the kernel core with the reference's own ChaCha12 stream (oracle_flat.cpp -DRT_RNG_REFSTREAM)."""
+    lib = declare_flat(C.CDLL(os.path.join(ORACLE_DIR, "liborc_flat_ref.so")))
+    assert lib.orcflat_is_refstream() == 1
+    return lib
 
 
 def declare_flat(lib):

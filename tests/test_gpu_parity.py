@@ -588,3 +588,34 @@ def test_c4_full_size_800x800_10000spp(rt, gpu_ctx_factory):
     b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=rt.default_chunk(W, H, spp))
     assert np.array_equal(full[300:302, 392:396], b, equal_nan=True)
     print(f"C4 full size: {st['total_ms'] / 1e3:.1f} s, {st['paths'] / st['total_ms'] / 1e3:.0f} Mpaths/s incl. D2H")
+
+
+def test_gpu_reference_stream_reproduces_the_reference_png(rt, gpu_ctx_factory):
+    """RT1W_RNG_REFERENCE: the HIP kernels drawing from the reference's own `StdRng::seed_from_u64(j*W+i)` (main.rs:964)
+    render the reference's shipped default (Cornell 600x600, 100 spp, depth 50, main.rs:868-870) and the quantised frame
+    is rest_of_your_life.png -- the Rust program's own output -- on every one of its 360 000 pixels (sha256 of the RGB
+    bytes + per-row crc32 from tests/golden/cornell_png_pixels.json).  Also: equal to the CPU build of the same core on a
+    crop, deterministic, and the default (Philox) frame is a different frame."""
+    import hashlib, zlib
+    pix = json.load(open(os.path.join(HERE, "golden", "cornell_png_pixels.json")))
+    sc = rt.Scene.reference(5, build_seed=1)
+    ctx = gpu_ctx_factory(sc)
+    u8, st = ctx.render_u8(600, 600, 100, reference_stream=True)
+    assert st["sorted"] & 16 and st["n_chunks"] == 1
+    bad = [r for r in range(600) if zlib.crc32(np.ascontiguousarray(u8[r]).tobytes()) != pix["row_crc32_top_down"][r]]
+    assert not bad, f"{len(bad)} rows differ from the reference PNG, first: {bad[:5]}"
+    assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).hexdigest() == pix["sha256_rgb_top_down"]
+    f64, _ = ctx.render(600, 600, 100, tile=(200, 300, 16, 8), reference_stream=True)
+    cpu, _ = orc.flat_render(sc, 600, 600, 100, tile=(200, 300, 16, 8), chunk=100, lib=orc.flat_ref_lib())
+    assert np.array_equal(f64, cpu)
+    again, _ = ctx.render_u8(600, 600, 100, reference_stream=True)
+    assert np.array_equal(again, u8)
+    philox, _ = ctx.render_u8(600, 600, 100)
+    assert (philox != u8).any()
+    with pytest.raises(rt.Rt1wError):
+        ctx.render(64, 64, 4, sample_offset=2, reference_stream=True)
+    # a big scene goes through the stack-walk build of the same kernel: equal to the CPU build of the core
+    big = rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5)
+    g, sg = gpu_ctx_factory(big).render(96, 64, 6, reference_stream=True)
+    c, sc_ = orc.flat_render(big, 96, 64, 6, chunk=6, lib=orc.flat_ref_lib(), variant=3)
+    assert sg["segments"] == sc_["segments"] and np.array_equal(g, c)

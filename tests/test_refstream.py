@@ -107,3 +107,17 @@ def test_philox_mode_matches_the_png_at_the_monte_carlo_noise_level():
     assert np.abs(d).max() < 0.15, d
     b = q.reshape(6, 100, 6, 100, 3).mean(axis=(1, 3)) - np.array(blocks["block_means_top_down"])
     assert np.abs(b).max() < 1.5, np.abs(b).max()
+
+
+def test_kernel_core_with_the_reference_stream_reproduces_the_png_crop(rt):
+    """The DEVICE core (rt_core.h + the flattened scene) compiled for the CPU with RT_RNG_REFSTREAM -- the same text
+    csrc/context_ref.hip builds for the GPU (RT1W_RNG_REFERENCE) -- on the committed crop of the reference's PNG: every
+    pixel equal.  The deterministic elementary functions of include/rt1w_num.h stand in for libm here, so this also shows
+    that an ulp in sin/cos/acos/atan2 does not reach a pixel."""
+    lib = orc.flat_ref_lib()
+    sc = rt.Scene.reference(5, build_seed=1)
+    x0, y0t, w, h = PIX["crop_top_down"]
+    tile = (x0, 600 - y0t - h, w, h)
+    img, _ = orc.flat_render(sc, 600, 600, 100, tile=tile, chunk=100, lib=lib)
+    q = rt.quantize(img)[::-1]
+    assert np.array_equal(q, CROP), float((q == CROP).all(axis=2).mean())
