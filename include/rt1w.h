@@ -185,6 +185,10 @@ typedef struct rt1w_render_params {
     uint32_t reserved;              /* must be 0 */
 } rt1w_render_params;
 #define RT1W_PRECISION_F64 0u
+/* the reference's switch set the other way, `type Float = f32`: rays, hit records, boxes, camera and colours in f32 (the
+ * random draws are still made in 64 bits and rounded, the elementary functions are evaluated in 64 bits and rounded once, a
+ * pixel's samples are summed in f64).  Statistically equal to the f64 frame, not bitwise; generic kernels only. */
+#define RT1W_PRECISION_F32 1u
 
 typedef struct rt1w_stats {
     uint64_t paths;        /* pixels * spp */

@@ -46,26 +46,50 @@
 #define RT_HD inline
 #endif
 
+/* The f32 build (RT1W_PRECISION_F32; csrc/context_f32.hip) compiles this header and the core with `double` redefined to
+ * `float` -- the reference's own switch, `type Float = f64` -> f32 (src/main.rs:1).  What must stay 64-bit there (bit
+ * tricks, the generator's conversions, the elementary functions' internals, the pixel sums) is spelled rt_f64, which that
+ * translation unit declares before it redefines `double`. */
+#if !defined(RT_F32)
+typedef double rt_f64;
+#endif
+
 /* ------------------------------------------------------------------ bits -- */
 
-RT_HD uint64_t rt_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
-RT_HD double rt_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+RT_HD uint64_t rt_d2u(rt_f64 x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+RT_HD rt_f64 rt_u2d(uint64_t u) { rt_f64 x; __builtin_memcpy(&x, &u, 8); return x; }
 
 #define RT_INF (__builtin_huge_val())
 #define RT_PI 3.14159265358979323846264338327950288
 
 RT_HD bool rt_isnan(double x) { return x != x; }
+RT_HD bool rt_isnan64(rt_f64 x) { return x != x; }
+#if defined(RT_F32)
+RT_HD double rt_abs(double x) { return __builtin_fabsf(x); }
+#else
 RT_HD double rt_abs(double x) { return rt_u2d(rt_d2u(x) & 0x7FFFFFFFFFFFFFFFull); }
+#endif
+RT_HD rt_f64 rt_abs64(rt_f64 x) { return rt_u2d(rt_d2u(x) & 0x7FFFFFFFFFFFFFFFull); }
 /* Rust f64::min / f64::max: if one operand is NaN the other is returned. */
 RT_HD double rt_min(double a, double b) { return (a < b || rt_isnan(b)) ? a : b; }
 RT_HD double rt_max(double a, double b) { return (a > b || rt_isnan(b)) ? a : b; }
+#if defined(RT_F32)
+RT_HD double rt_sqrt(double x) { return __builtin_sqrtf(x); }
+#else
 RT_HD double rt_sqrt(double x) { return __builtin_sqrt(x); }
+#endif
+RT_HD rt_f64 rt_sqrt64(rt_f64 x) { return __builtin_sqrt(x); }
 /* floor without libm: |x| >= 2^52 is already integral. */
-RT_HD double rt_floor(double x) {
-    if (!(rt_abs(x) < 4503599627370496.0)) return x;
-    double t = (double)(int64_t)x; /* truncates toward zero */
+RT_HD rt_f64 rt_floor64(rt_f64 x) {
+    if (!(rt_abs64(x) < 4503599627370496.0)) return x;
+    rt_f64 t = (rt_f64)(int64_t)x; /* truncates toward zero */
     return (t > x) ? t - 1.0 : t;
 }
+#if defined(RT_F32)
+RT_HD double rt_floor(double x) { return (double)rt_floor64((rt_f64)x); } /* exact: the floor of a float is a float */
+#else
+RT_HD double rt_floor(double x) { return rt_floor64(x); }
+#endif
 
 /* --------------------------------------------------------- Philox4x32-10 -- */
 
@@ -233,16 +257,16 @@ RT_HD uint32_t rt_next_u32(RtRng& r) { rt_rng_reserve(r, 1u); return rt_take_u32
 RT_HD uint64_t rt_next_u64(RtRng& r) { rt_rng_reserve(r, rt_rng_need_u64(r)); return rt_take_u64(r); }
 
 /* rand 0.8 `rng.gen::<f64>()`: 53 random bits scaled into [0,1). */
-RT_HD double rt_gen_f64(RtRng& r) {
-    return (double)(rt_next_u64(r) >> 11) * (1.0 / 9007199254740992.0);
+RT_HD rt_f64 rt_gen_f64(RtRng& r) {
+    return (rt_f64)(rt_next_u64(r) >> 11) * (1.0 / 9007199254740992.0);
 }
 /* rand 0.8 `rng.gen_range(low..high)` for f64 (UniformFloat::sample_single):
  * 52 mantissa bits -> [1,2) -> minus 1 -> *scale + low, retry if >= high. */
-RT_HD double rt_gen_range(RtRng& r, double low, double high) {
-    double scale = high - low;
+RT_HD rt_f64 rt_gen_range(RtRng& r, rt_f64 low, rt_f64 high) {
+    rt_f64 scale = high - low;
     for (;;) {
-        double v12 = rt_u2d((rt_next_u64(r) >> 12) | 0x3FF0000000000000ull);
-        double res = (v12 - 1.0) * scale + low;
+        rt_f64 v12 = rt_u2d((rt_next_u64(r) >> 12) | 0x3FF0000000000000ull);
+        rt_f64 res = (v12 - 1.0) * scale + low;
         if (res < high) return res;
     }
 }
@@ -261,18 +285,18 @@ RT_HD uint32_t rt_gen_below(RtRng& r, uint32_t n) {
 }
 
 /* conversions of one 64-bit draw (rand 0.8 Standard f64 / UniformFloat) */
-RT_HD double rt_f64_from_bits(uint64_t q) { return (double)(q >> 11) * (1.0 / 9007199254740992.0); }
-RT_HD double rt_range_from_bits(uint64_t q, double low, double high) {
-    double scale = high - low;
-    double v12 = rt_u2d((q >> 12) | 0x3FF0000000000000ull);
+RT_HD rt_f64 rt_f64_from_bits(uint64_t q) { return (rt_f64)(q >> 11) * (1.0 / 9007199254740992.0); }
+RT_HD rt_f64 rt_range_from_bits(uint64_t q, rt_f64 low, rt_f64 high) {
+    rt_f64 scale = high - low;
+    rt_f64 v12 = rt_u2d((q >> 12) | 0x3FF0000000000000ull);
     return (v12 - 1.0) * scale + low;
 }
 /* ---- the same shapes over reserved words (device core; see rt_rng_reserve) ---- */
-RT_HD double rt_take_f64(RtRng& r) { return (double)(rt_take_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
-RT_HD double rt_take_range(RtRng& r, double low, double high) {
-    double scale = high - low;
-    double v12 = rt_u2d((rt_take_u64(r) >> 12) | 0x3FF0000000000000ull);
-    double res = (v12 - 1.0) * scale + low;
+RT_HD rt_f64 rt_take_f64(RtRng& r) { return (rt_f64)(rt_take_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
+RT_HD rt_f64 rt_take_range(RtRng& r, rt_f64 low, rt_f64 high) {
+    rt_f64 scale = high - low;
+    rt_f64 v12 = rt_u2d((rt_take_u64(r) >> 12) | 0x3FF0000000000000ull);
+    rt_f64 res = (v12 - 1.0) * scale + low;
     while (!(res < high)) { /* rounding pushed the value onto `high`: draw again (checked) */
         v12 = rt_u2d((rt_next_u64(r) >> 12) | 0x3FF0000000000000ull);
         res = (v12 - 1.0) * scale + low;
@@ -288,55 +312,55 @@ RT_HD bool rt_take_bool(RtRng& r) { return (int32_t)rt_take_u32(r) < 0; }
  * <= 2 ulp. */
 
 /* kernel sin/cos on [-pi/4, pi/4] (fdlibm minimax polynomials, degree 13/14) */
-RT_HD double rt_ksin(double x, double y) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+RT_HD rt_f64 rt_ksin(rt_f64 x, rt_f64 y) {
+    const rt_f64 S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = x * x;
-    double v = z * x;
-    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    rt_f64 z = x * x;
+    rt_f64 v = z * x;
+    rt_f64 r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
     return x - ((z * (0.5 * y - v * r) - y) - v * S1);
 }
-RT_HD double rt_kcos(double x, double y) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+RT_HD rt_f64 rt_kcos(rt_f64 x, rt_f64 y) {
+    const rt_f64 C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = x * x;
-    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    double hz = 0.5 * z;
-    double w = 1.0 - hz;
+    rt_f64 z = x * x;
+    rt_f64 r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    rt_f64 hz = 0.5 * z;
+    rt_f64 w = 1.0 - hz;
     return w + (((1.0 - w) - hz) + (z * r - x * y));
 }
 /* Cody-Waite reduction by pi/2 in three 33-bit pieces; exact products for
  * |n| < 2^20, i.e. |x| < ~1.6e6 (accuracy degrades gradually beyond; callers
  * return NaN for |x| >= 2^30, far outside any scene's coordinates, so the
- * double->integer conversion below is always in range on both targets).
+ * rt_f64->integer conversion below is always in range on both targets).
  * Returns quadrant (0..3), remainder in (hi, lo). */
-struct RtRem { double hi, lo; int n; };
-RT_HD RtRem rt_rem_pio2(double x) {
-    const double INVPIO2 = 6.36619772367581382433e-01;
-    const double P1 = 1.57079632673412561417e+00;  /* 0x3FF921FB54400000 */
-    const double P1T = 6.07710050650619224932e-11;
-    const double P2 = 6.07710050630396597660e-11;  /* 0x3DD0B4611A600000 */
-    const double P2T = 2.02226624879595063154e-21;
-    const double P3 = 2.02226624871116645580e-21;  /* 0x3BA3198A2E000000 */
-    const double P3T = 8.47842766036889956997e-32;
-    double t = x * INVPIO2;
-    double fn = rt_floor(t + 0.5);
+struct RtRem { rt_f64 hi, lo; int n; };
+RT_HD RtRem rt_rem_pio2(rt_f64 x) {
+    const rt_f64 INVPIO2 = 6.36619772367581382433e-01;
+    const rt_f64 P1 = 1.57079632673412561417e+00;  /* 0x3FF921FB54400000 */
+    const rt_f64 P1T = 6.07710050650619224932e-11;
+    const rt_f64 P2 = 6.07710050630396597660e-11;  /* 0x3DD0B4611A600000 */
+    const rt_f64 P2T = 2.02226624879595063154e-21;
+    const rt_f64 P3 = 2.02226624871116645580e-21;  /* 0x3BA3198A2E000000 */
+    const rt_f64 P3T = 8.47842766036889956997e-32;
+    rt_f64 t = x * INVPIO2;
+    rt_f64 fn = rt_floor64(t + 0.5);
     int n = (int)((int64_t)fn & 3);
     /* three-stage subtraction, keeping a tail */
-    double r = x - fn * P1;
-    double w;
-    double y0;
+    rt_f64 r = x - fn * P1;
+    rt_f64 w;
+    rt_f64 y0;
     /* second iteration (always; cost is small, accuracy uniform) */
-    double t2 = r;
+    rt_f64 t2 = r;
     w = fn * P2;
     r = t2 - w;
     w = fn * P2T - ((t2 - r) - w);
     y0 = r - w;
     /* third iteration */
-    double t3 = r;
-    double w3 = fn * P3;
+    rt_f64 t3 = r;
+    rt_f64 w3 = fn * P3;
     r = t3 - w3;
     w = fn * P3T - ((t3 - r) - w3);
     y0 = r - w;
@@ -347,18 +371,18 @@ RT_HD RtRem rt_rem_pio2(double x) {
     return o;
 }
 #define RT_TRIG_MAX 1073741824.0 /* 2^30 */
-RT_HD double rt_sin(double x) {
-    if (rt_abs(x) < 0.78539816339744830962) return rt_ksin(x, 0.0);
-    if (!(rt_abs(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
+RT_HD rt_f64 rt_sin(rt_f64 x) {
+    if (rt_abs64(x) < 0.78539816339744830962) return rt_ksin(x, 0.0);
+    if (!(rt_abs64(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
     RtRem q = rt_rem_pio2(x);
     if (q.n == 0) return rt_ksin(q.hi, q.lo);
     if (q.n == 1) return rt_kcos(q.hi, q.lo);
     if (q.n == 2) return -rt_ksin(q.hi, q.lo);
     return -rt_kcos(q.hi, q.lo);
 }
-RT_HD double rt_cos(double x) {
-    if (rt_abs(x) < 0.78539816339744830962) return rt_kcos(x, 0.0);
-    if (!(rt_abs(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
+RT_HD rt_f64 rt_cos(rt_f64 x) {
+    if (rt_abs64(x) < 0.78539816339744830962) return rt_kcos(x, 0.0);
+    if (!(rt_abs64(x) < RT_TRIG_MAX)) return rt_u2d(0x7FF8000000000000ull);
     RtRem q = rt_rem_pio2(x);
     if (q.n == 0) return rt_kcos(q.hi, q.lo);
     if (q.n == 1) return -rt_ksin(q.hi, q.lo);
@@ -366,26 +390,26 @@ RT_HD double rt_cos(double x) {
     return rt_ksin(q.hi, q.lo);
 }
 /* sin and cos of one argument with one shared reduction (same values as above) */
-RT_HD void rt_sincos(double x, double& s, double& c) {
-    double hi = x, lo = 0.0;
+RT_HD void rt_sincos(rt_f64 x, rt_f64& s, rt_f64& c) {
+    rt_f64 hi = x, lo = 0.0;
     int n = 0;
-    if (!(rt_abs(x) < RT_TRIG_MAX)) { s = c = rt_u2d(0x7FF8000000000000ull); return; }
-    if (!(rt_abs(x) < 0.78539816339744830962)) { RtRem q = rt_rem_pio2(x); hi = q.hi; lo = q.lo; n = q.n; }
-    double ks = rt_ksin(hi, lo), kc = rt_kcos(hi, lo);
+    if (!(rt_abs64(x) < RT_TRIG_MAX)) { s = c = rt_u2d(0x7FF8000000000000ull); return; }
+    if (!(rt_abs64(x) < 0.78539816339744830962)) { RtRem q = rt_rem_pio2(x); hi = q.hi; lo = q.lo; n = q.n; }
+    rt_f64 ks = rt_ksin(hi, lo), kc = rt_kcos(hi, lo);
     s = (n == 0) ? ks : (n == 1) ? kc : (n == 2) ? -ks : -kc;
     c = (n == 0) ? kc : (n == 1) ? -ks : (n == 2) ? -kc : ks;
 }
-RT_HD double rt_tan(double x) { double s, c; rt_sincos(x, s, c); return s / c; }
+RT_HD rt_f64 rt_tan(rt_f64 x) { rt_f64 s, c; rt_sincos(x, s, c); return s / c; }
 
 /* atan for x >= 0 (fdlibm breakpoints 7/16, 11/16, 19/16, 39/16) */
-RT_HD double rt_atan_pos(double x) {
-    const double AT0 = 3.33333333333329318027e-01, AT1 = -1.99999999998764832476e-01,
+RT_HD rt_f64 rt_atan_pos(rt_f64 x) {
+    const rt_f64 AT0 = 3.33333333333329318027e-01, AT1 = -1.99999999998764832476e-01,
                  AT2 = 1.42857142725034663711e-01, AT3 = -1.11111104054623557880e-01,
                  AT4 = 9.09088713343650656196e-02, AT5 = -7.69187620504482999495e-02,
                  AT6 = 6.66107313738753120669e-02, AT7 = -5.83357013379057348645e-02,
                  AT8 = 4.97687799461593236017e-02, AT9 = -3.65315727442169155270e-02,
                  AT10 = 1.62858201153657823623e-02;
-    double hi, lo;
+    rt_f64 hi, lo;
     if (x < 0.4375) { hi = 0.0; lo = 0.0; }
     else if (x < 0.6875) { hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17;
                            x = (2.0 * x - 1.0) / (2.0 + x); }
@@ -395,42 +419,42 @@ RT_HD double rt_atan_pos(double x) {
                            x = (x - 1.5) / (1.0 + 1.5 * x); }
     else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17;
            x = -1.0 / x; }
-    double z = x * x;
-    double w = z * z;
-    double s1 = z * (AT0 + w * (AT2 + w * (AT4 + w * (AT6 + w * (AT8 + w * AT10)))));
-    double s2 = w * (AT1 + w * (AT3 + w * (AT5 + w * (AT7 + w * AT9))));
+    rt_f64 z = x * x;
+    rt_f64 w = z * z;
+    rt_f64 s1 = z * (AT0 + w * (AT2 + w * (AT4 + w * (AT6 + w * (AT8 + w * AT10)))));
+    rt_f64 s2 = w * (AT1 + w * (AT3 + w * (AT5 + w * (AT7 + w * AT9))));
     if (hi == 0.0) return x - x * (s1 + s2);
     return hi - ((x * (s1 + s2) - lo) - x);
 }
-RT_HD double rt_atan2(double y, double x) {
-    const double PI_LO = 1.2246467991473531772e-16;
-    if (rt_isnan(x) || rt_isnan(y)) return x + y;
+RT_HD rt_f64 rt_atan2(rt_f64 y, rt_f64 x) {
+    const rt_f64 PI_LO = 1.2246467991473531772e-16;
+    if (rt_isnan64(x) || rt_isnan64(y)) return x + y;
     bool yneg = (rt_d2u(y) >> 63) != 0, xneg = (rt_d2u(x) >> 63) != 0;
-    double ay = rt_abs(y), ax = rt_abs(x);
+    rt_f64 ay = rt_abs64(y), ax = rt_abs64(x);
     if (ay == 0.0) return xneg ? (yneg ? -RT_PI : RT_PI) : y;
     if (ax == 0.0) return yneg ? -1.57079632679489655800e+00 : 1.57079632679489655800e+00;
-    double z;
+    rt_f64 z;
     if (ax == RT_INF && ay == RT_INF) z = 7.85398163397448278999e-01;
     else if (ax == RT_INF) z = 0.0;
     else if (ay == RT_INF) z = 1.57079632679489655800e+00;
     else z = rt_atan_pos(ay / ax);
     if (!xneg) return yneg ? -z : z;
-    double r = RT_PI - (z - PI_LO);
+    rt_f64 r = RT_PI - (z - PI_LO);
     return yneg ? -r : r;
 }
 /* acos(x) = 2*atan2(sqrt(1-x), sqrt(1+x)) -- benign cancellation only */
-RT_HD double rt_acos(double x) {
+RT_HD rt_f64 rt_acos(rt_f64 x) {
     if (!(x >= -1.0 && x <= 1.0)) return rt_u2d(0x7FF8000000000000ull);
-    return 2.0 * rt_atan2(rt_sqrt(1.0 - x), rt_sqrt(1.0 + x));
+    return 2.0 * rt_atan2(rt_sqrt64(1.0 - x), rt_sqrt64(1.0 + x));
 }
 /* natural log (fdlibm): x = 2^k * (1+f), sqrt(1/2) < 1+f < sqrt(2) */
-RT_HD double rt_log(double x) {
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
+RT_HD rt_f64 rt_log(rt_f64 x) {
+    const rt_f64 LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const rt_f64 LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
                  LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
                  LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
                  LG7 = 1.479819860511658591e-01;
-    if (rt_isnan(x)) return x;
+    if (rt_isnan64(x)) return x;
     if (x < 0.0) return rt_u2d(0x7FF8000000000000ull);
     if (x == 0.0) return -RT_INF;
     if (x == RT_INF) return x;
@@ -439,21 +463,26 @@ RT_HD double rt_log(double x) {
     if ((u >> 52) == 0) { x = x * 18014398509481984.0; k -= 54; u = rt_d2u(x); } /* subnormal */
     k += (int)((u >> 52) & 0x7FF) - 1023;
     u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
-    double m = rt_u2d(u);
+    rt_f64 m = rt_u2d(u);
     if (m > 1.41421356237309504880) { m = m * 0.5; k += 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double w = z * z;
-    double t1 = w * (LG2 + w * (LG4 + w * LG6));
-    double t2 = z * (LG1 + w * (LG3 + w * (LG5 + w * LG7)));
-    double R = t2 + t1;
-    double hfsq = 0.5 * f * f;
-    double dk = (double)k;
+    rt_f64 f = m - 1.0;
+    rt_f64 s = f / (2.0 + f);
+    rt_f64 z = s * s;
+    rt_f64 w = z * z;
+    rt_f64 t1 = w * (LG2 + w * (LG4 + w * LG6));
+    rt_f64 t2 = z * (LG1 + w * (LG3 + w * (LG5 + w * LG7)));
+    rt_f64 R = t2 + t1;
+    rt_f64 hfsq = 0.5 * f * f;
+    rt_f64 dk = (rt_f64)k;
     return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
 }
 /* x.powf(5.0) of src/material.rs:124, as a fixed multiplication chain */
 RT_HD double rt_pow5(double x) { double x2 = x * x; return (x2 * x2) * x; }
+
+#if defined(RT_F32)
+/* f32 build: the callers hold floats; the functions above run in 64 bits and the result is rounded once */
+RT_HD void rt_sincos(double x, double& s, double& c) { rt_f64 s64, c64; rt_sincos((rt_f64)x, s64, c64); s = (double)s64; c = (double)c64; }
+#endif
 
 /* ------------------------------------------------------------------ vec3 -- */
 /* cgmath 0.18 semantics (un-vendored; restated): element-wise ops,
@@ -477,5 +506,9 @@ RT_HD RtV3 rt_cross(RtV3 a, RtV3 b) {
     return rt_v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 RT_HD double rt_get(RtV3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+/* sums of a pixel's samples: 64-bit in every build (src/main.rs:972-989 adds Float's; the f32 build keeps the sum wider) */
+struct RtV3d { rt_f64 x, y, z; };
+RT_HD RtV3d rt_v3d(rt_f64 x, rt_f64 y, rt_f64 z) { RtV3d v; v.x = x; v.y = y; v.z = z; return v; }
+RT_HD RtV3d rt_v3d_add(RtV3d a, RtV3 b) { return rt_v3d(a.x + (rt_f64)b.x, a.y + (rt_f64)b.y, a.z + (rt_f64)b.z); }
 
 #endif /* RT1W_NUM_H */

@@ -38,6 +38,14 @@ extern "C" int rt1w_internal_ref_blocks_per_cu(int stack_walk);
 extern "C" int rt1w_internal_ref_launch(int stack_walk, const void* view, const void* frame, double* partial, unsigned long long* counters,
                                         int grid, hipStream_t stream);
 extern "C" unsigned rt1w_internal_ref_sizeof(int what);
+/* context_f32.hip: the kernels in single precision (RT1W_PRECISION_F32) and the f32 copies of the scene arrays */
+extern "C" int rt1w_internal_f32_create(const void* nodes, uint32_t n_nodes, const void* lights, uint32_t n_lights, const void* materials,
+                                        uint32_t n_materials, const void* textures, uint32_t n_textures, const void* perlin, uint32_t n_perlin,
+                                        const void* view64, void** out);
+extern "C" void rt1w_internal_f32_destroy(void* h);
+extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted);
+extern "C" int rt1w_internal_f32_launch(void* h, int variant, int sorted, const void* frame, double* partial, unsigned long long* counters, int grid,
+                                        hipStream_t stream);
 
 namespace {
 
@@ -156,6 +164,8 @@ struct rt1w_context {
     int wf_grid_trace[18] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
     uint32_t stack_need = 0;
     int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
+    void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays */
+    int f32_grid[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
     hipModule_t jit_mod = nullptr;
@@ -196,7 +206,7 @@ int validate(const rt1w_context* c, const rt1w_render_params* p) {
         rt1w::set_error("strip_rows / strip_period: both 0, or 0 < strip_rows <= strip_period"); return RT1W_ERR_INVALID;
     }
     if (p->reserved != 0u) { rt1w::set_error("rt1w_render_params.reserved must be 0"); return RT1W_ERR_INVALID; }
-    if (p->precision != RT1W_PRECISION_F64) { rt1w::set_error("unknown precision"); return RT1W_ERR_UNSUPPORTED; }
+    if (p->precision != RT1W_PRECISION_F64 && p->precision != RT1W_PRECISION_F32) { rt1w::set_error("unknown precision"); return RT1W_ERR_UNSUPPORTED; }
     if (p->strip_rows) {
         const uint64_t last = (uint64_t)p->tile_h - 1u;
         const uint64_t j = (uint64_t)p->y0 + (last / p->strip_rows) * p->strip_period + last % p->strip_rows;
@@ -229,7 +239,7 @@ void lane_destroy(RtLane& l) {
     l = RtLane();
 }
 
-struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref; };
+struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32; };
 
 /* what the launch will need, without launching: frame, variant, launch shape */
 int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
@@ -243,7 +253,26 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     if (f.chunk > f.spp) f.chunk = f.spp;
     f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
     L.npix = (unsigned long long)f.tile_w * f.tile_h;
-    L.ref = false;
+    L.ref = false; L.f32 = false;
+    if (p->precision == RT1W_PRECISION_F32) {
+        if (p->flags & (RT1W_RNG_REFERENCE | RT1W_WAVEFRONT | RT1W_LDS_NODES)) { rt1w::set_error("RT1W_PRECISION_F32 has the default kernels only"); return RT1W_ERR_INVALID; }
+        int v = c->variant > 3 ? 3 : c->variant;
+        if (p->flags >> 8) {
+            v = (int)((p->flags >> 8) & 0xFFu) - 1;
+            if (v > 3 || !rt_variant_valid(v, c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth)) {
+                rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
+            }
+        }
+        const bool sorted = v < 2 && !(p->flags & RT1W_UNSORTED);
+        int& g = c->f32_grid[v][sorted ? 1 : 0];
+        if (!g) {
+            hipDeviceProp_t prop;
+            if (!hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
+            g = prop.multiProcessorCount * rt1w_internal_f32_blocks_per_cu(v, sorted ? 1 : 0);
+        }
+        L.f32 = true; L.jit = false; L.sorted = sorted; L.cached = false; L.variant = v; L.grid = g; L.block = sorted ? RT_SORT_BLOCK : RT_BLOCK;
+        return RT1W_OK;
+    }
     if (p->flags & RT1W_RNG_REFERENCE) {
         /* the reference's own stream: one lane owns a pixel for all its samples (main.rs:964-989) */
         if (p->sample_offset != 0u) { rt1w::set_error("RT1W_RNG_REFERENCE: one stream per pixel, sample_offset must be 0"); return RT1W_ERR_INVALID; }
@@ -290,7 +319,11 @@ int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
 int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const RtLaunch& L, double* d_out) {
     hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block);
     (void)hipEventRecord(l.ev0, l.stream);
-    if (L.ref) {
+    if (L.f32) {
+        if (!c->f32_scene || rt1w_internal_f32_launch(c->f32_scene, L.variant, L.sorted ? 1 : 0, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
+            rt1w::set_error("single-precision kernel launch failed"); return RT1W_ERR_DEVICE;
+        }
+    } else if (L.ref) {
         if (rt1w_internal_ref_sizeof(0) != sizeof(RtSceneView) || rt1w_internal_ref_sizeof(1) != sizeof(RtFrame) ||
             rt1w_internal_ref_launch(L.variant == 3 ? 1 : 0, &c->view, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
             rt1w::set_error("reference-stream kernel launch failed"); return RT1W_ERR_DEVICE;
@@ -329,7 +362,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u);
     }
     return RT1W_OK;
 }
@@ -502,7 +535,7 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
     if (rc < 0) return rc;
     RtLane& l = c->lane[0];
     if ((rc = lane_reserve_partial(l, L)) < 0) return rc;
-    if ((p->flags & RT1W_WAVEFRONT) && !L.jit && !L.sorted && !L.ref) return render_wavefront(c, p, L, d_out, stats);
+    if ((p->flags & RT1W_WAVEFRONT) && !L.jit && !L.sorted && !L.ref && !L.f32) return render_wavefront(c, p, L, d_out, stats);
     if ((rc = render_launch(c, l, p, L, d_out)) < 0) return rc;
     return render_finish(l, L, stats);
 }
@@ -596,6 +629,11 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->scope_depth = s->scope_depth;
     c->stack_need = s->stack_need;
     c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth, s->walk_order != 0u);
+    if (rt1w_internal_f32_create(s->flat_nodes.data(), (uint32_t)s->flat_nodes.size(), s->flat_lights.data(), (uint32_t)s->flat_lights.size(),
+                                 s->materials.data(), (uint32_t)s->materials.size(), s->textures.data(), (uint32_t)s->textures.size(),
+                                 s->perlin.data(), (uint32_t)s->perlin.size(), &c->view, &c->f32_scene) != 0) {
+        rt1w::set_error("could not build the single-precision scene arrays"); rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+    }
     if (c->variant >= 2) {
         /* walk records for the wavefront form: eligible when every MovingSphere has the same (time0, time1) */
         std::vector<WfRec> recs(s->flat_nodes.size());
@@ -634,6 +672,7 @@ void rt1w_context_destroy(rt1w_context* c) {
                     c->wf_q[0].f, c->wf_q[0].u, c->wf_q[1].f, c->wf_q[1].u, c->wf_rad, c->wf_counters, c->d_wf_recs};
     if (c->wf_hcounters) (void)hipHostFree(c->wf_hcounters);
     for (void* b : bufs) if (b) (void)hipFree(b);
+    rt1w_internal_f32_destroy(c->f32_scene);
     lane_destroy(c->lane[0]);
     lane_destroy(c->lane[1]);
     if (c->jit_mod) (void)hipModuleUnload(c->jit_mod);

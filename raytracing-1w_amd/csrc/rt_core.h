@@ -100,7 +100,10 @@ RT_HD bool rt_aabb_hit(const double* bb, RtV3 o, RtV3 inv, double t_min, double 
  * is NaN and so does maxNum; equal values or zeros of either sign give the same comparisons
  * afterwards (t_min, t_max are not outputs).  Callers take the literal form when a NaN bound
  * is present (a NaN root was accepted earlier -- reference behaviour, reproduced). */
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_ASM_MINMAX)
+#if defined(RT_F32)
+RT_HD double rt_vmax(double a, double b) { return __builtin_fmaxf(a, b); }
+RT_HD double rt_vmin(double a, double b) { return __builtin_fminf(a, b); }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_ASM_MINMAX)
 /* the bare instructions: __builtin_fmax/fmin make the compiler canonicalise each operand first
  * (a v_max_f64 x,x,x apiece); every operand here is an arithmetic result or a previous max/min */
 RT_HD double rt_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

@@ -27,7 +27,7 @@ struct LdsNodes {
 #endif
 #define RT_PLAIN_WAVES(Cfg, CACHE) (Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : (Cfg::sweep || CACHE ? 2 : 3))
 template <class Cfg, bool CACHE>
-__device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, const RtFrame& f, double* __restrict__ partial,
+__device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
                                                      unsigned long long* __restrict__ counters) {
     /* the sweep variants need no traversal stack (and no LDS at all) */
     typedef typename std::conditional<CACHE, uint16_t, uint32_t>::type stack_word;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
     bool fresh = true; /* `item` holds an id that was not decoded yet */
     bool have = false;
     uint32_t px = 0, py = 0, chunk = 0, s = 0, s_end = 0;
-    RtV3 sum = rt_v3(0.0, 0.0, 0.0);
+    RtV3d sum = rt_v3d(0.0, 0.0, 0.0);
     RtPath path;
     path.alive = false;
     unsigned long long segs = 0;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
         RT_STAMP(0);
         if (!path.alive) {
             if (have && s == s_end) {
-                double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
+                rt_f64* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
                 dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
                 have = false;
             }
@@ -92,7 +92,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 if (px < f.tile_w && py < f.tile_h) {
                     s = chunk * f.chunk;
                     s_end = s + f.chunk < f.spp ? s + f.chunk : f.spp;
-                    sum = rt_v3(0.0, 0.0, 0.0);
+                    sum = rt_v3d(0.0, 0.0, 0.0);
                     have = true;
                 }
             }
@@ -103,7 +103,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
         segs += path.depth_left != 0u ? 1ull : 0ull;
         rt_path_step<Cfg>(sc, ns, path, stk);
         if (!path.alive) {
-            sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
+            sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
             ++s;
         }
         RT_STAMP(6);

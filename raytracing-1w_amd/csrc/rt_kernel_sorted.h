@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 #endif
 #define RT_SORT_WAVES(Cfg) ((Cfg::sweep && !Cfg::media) ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2) /* waves per SIMD the kernel is built for */
 template <class Cfg>
-__device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, const RtFrame& f, double* __restrict__ partial,
+__device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
                                                       unsigned long long* __restrict__ counters) {
     constexpr int NW = RT_SORT_BLOCK / 64;
     static_assert(Cfg::sweep, "the reordering kernel is built for the stackless variants");
@@ -72,7 +72,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
     unsigned long long item = (unsigned long long)blockIdx.x * RT_SORT_BLOCK + threadIdx.x;
     bool fresh = true, have = false, retired = false;
     uint32_t px = 0, py = 0, chunk = 0, s = 0;
-    RtV3 sum = rt_v3(0.0, 0.0, 0.0);
+    RtV3d sum = rt_v3d(0.0, 0.0, 0.0);
     RtPath path;
     path.alive = false;
     path.depth_left = 0u;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
         if (!path.alive && !retired) {
             uint32_t s_end = chunk * f.chunk + f.chunk < f.spp ? chunk * f.chunk + f.chunk : f.spp;
             if (have && s == s_end) {
-                double* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
+                rt_f64* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
                 dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
                 have = false;
             }
@@ -113,7 +113,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
                 rt_item_decode(f, item, px, py, chunk);
                 if (px < f.tile_w && py < f.tile_h) {
                     s = chunk * f.chunk;
-                    sum = rt_v3(0.0, 0.0, 0.0);
+                    sum = rt_v3d(0.0, 0.0, 0.0);
                     have = true;
                 }
             }
@@ -206,7 +206,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
         if (!retired) {
             rt_path_shade<Cfg>(sc, path, tr);
             if (!path.alive) {
-                sum = sum + path.radiance; /* pixel_color += ray_color(..), main.rs:972-989 */
+                sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
                 path.radiance = rt_v3(0.0, 0.0, 0.0);
                 ++s;
             }

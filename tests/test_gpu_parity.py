@@ -619,3 +619,36 @@ def test_gpu_reference_stream_reproduces_the_reference_png(rt, gpu_ctx_factory):
     g, sg = gpu_ctx_factory(big).render(96, 64, 6, reference_stream=True)
     c, sc_ = orc.flat_render(big, 96, 64, 6, chunk=6, lib=orc.flat_ref_lib(), variant=3)
     assert sg["segments"] == sc_["segments"] and np.array_equal(g, c)
+
+
+def test_f32_mode_matches_the_f64_frame_statistically(rt, gpu_ctx_factory):
+    """RT1W_PRECISION_F32 (the reference's `type Float = f32`, main.rs:1): same scene, same streams, f32
+    arithmetic.  Parity is statistical: at 600x600x256 spp the 8-bit 100x100-block means of the f32 and f64 frames agree
+    within 1/255 (measured 0.65) and the global channel means within 0.1/255 (the two frames share their random numbers, so most paths
+    are the same paths and the difference is far below the Monte-Carlo noise of either); no NaN pixel, and at most a handful of pixels zeroed by the reference's NaN
+    scrub that the f64 frame does not have (measured 8 of 360 000); and explicitly at the reference's thin spots: the k = 555 walls, whose BVH boxes are
+    0.0001 thick (aarect.rs:74-79) = 1.6 f32 ulps -- the rows and columns next to the walls show no holes (their means
+    stay within 2 % of the f64 frame's) -- and t_min = 0.001 (main.rs:62): no acne, i.e. the floor's mean is unchanged."""
+    ctx = gpu_ctx_factory(rt.Scene.reference(5, build_seed=1))
+    W = H = 600
+    a, sa = ctx.render(W, H, 256)
+    b, sb = ctx.render(W, H, 256, f32=True)
+    assert sb["sorted"] & 32 and np.isfinite(b).all()
+    assert abs(sb["segments"] / sa["segments"] - 1.0) < 0.03          # f32 paths run 1.5 % longer (measured)
+    qa, qb = rt.quantize(a).astype(np.float64), rt.quantize(b).astype(np.float64)
+    assert np.abs(qa.mean(axis=(0, 1)) - qb.mean(axis=(0, 1))).max() < 0.1
+    blocks = (qa - qb).reshape(6, 100, 6, 100, 3).mean(axis=(1, 3))
+    assert np.abs(blocks).max() < 1.0, np.abs(blocks).max()          # measured 0.65
+    assert int(((b == 0).all(axis=2) & ~(a == 0).all(axis=2)).sum()) <= 40   # NaN-scrubbed pixels (color.rs:16-18): measured 8 of 360 000
+    for sl in (np.s_[:, 5:25], np.s_[:, -25:-5], np.s_[5:25, :], np.s_[-25:-5, :]):      # next to the four walls in the picture
+        ra, rb = a[sl].mean(), b[sl].mean()
+        assert abs(rb / ra - 1.0) < 0.03, (ra, rb)
+    # every arm renders in f32 and stays close to its f64 frame
+    for arm, aspect, (w, h, spp) in ((0, 1.5, (240, 160, 32)), (6, None, (128, 128, 32)), (7, None, (128, 128, 32)), (2, None, (128, 72, 16))):
+        c = gpu_ctx_factory(rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect))
+        x, _ = c.render(w, h, spp)
+        y, sy = c.render(w, h, spp, f32=True)
+        assert sy["sorted"] & 32 and np.isfinite(y).all()
+        assert abs(y.mean() / x.mean() - 1.0) < 0.03, (arm, x.mean(), y.mean())
+    with pytest.raises(rt.Rt1wError):
+        ctx.render(64, 64, 4, f32=True, reference_stream=True)
