@@ -53,7 +53,11 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 #ifndef RT_SORT_BLOCK
 #define RT_SORT_BLOCK 256 /* paths sorted together = workgroup size of the reordering kernel */
 #endif
+#ifdef RT_SORT_WAVES_OVERRIDE /* experiments (RT1W_JIT_EXTRA_OPTS=-DRT_SORT_WAVES_OVERRIDE=4) */
+#define RT_SORT_WAVES(Cfg) RT_SORT_WAVES_OVERRIDE
+#else
 #define RT_SORT_WAVES(Cfg) ((Cfg::sweep && !Cfg::media) ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2) /* waves per SIMD the kernel is built for */
+#endif
 template <class Cfg>
 __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
                                                       unsigned long long* __restrict__ counters) {
