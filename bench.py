@@ -43,7 +43,14 @@ def cpu_baseline(width, height):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     sc = orc.OracleScene(5, build_seed=1, aspect_ratio=width / height)
-    cores = os.cpu_count() or 1
+    # host cores this process may use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a share)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
 
     def run(threads, budget_s):
         spp = 2
@@ -60,7 +67,7 @@ def cpu_baseline(width, height):
     v_one, spp_one, paths_one, dt_one = run(1, 8.0)
     return {"value": round(v_all, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
             "sample": f"cornell_box {width}x{height}, {spp_all} spp, depth {DEPTH} ({paths_all} paths in {dt_all:.1f} s on a "
-                      f"std::thread pool of {cores} = os.cpu_count(); oracle built -O3)",
+                      f"std::thread pool of {cores} = the cores this job may use (affinity / cgroup quota; os.cpu_count() = {os.cpu_count()}); oracle built -O3)",
             "single_thread": {"value": round(v_one, 4), "cores": 1,
                               "sample": f"{spp_one} spp ({paths_one} paths in {dt_one:.1f} s)"}}
 

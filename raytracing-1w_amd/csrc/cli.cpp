@@ -5,6 +5,10 @@
  * values as defaults.
  *   rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B]
  *        [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic]
+ *        [--reference-stream] [--f32] [--near-far]
+ * --reference-stream draws from the reference's own StdRng per pixel (RT1W_RNG_REFERENCE): `rt1w --reference-stream` prints
+ * what `cargo run` of the reference prints, byte for byte (Cornell arm, 600x600, 100 spp).  --f32: RT1W_PRECISION_F32.
+ * --near-far: rt1w_scene_set_walk_order(RT1W_WALK_NEAR_FAR).
  * --specialise compiles the kernel for this scene's topology now if the kernel cache has none (rt1w_context_specialise;
  * by default only a cached kernel is used, and renders of >= 2^35 paths compile on their own); --generic forbids it.
  */
@@ -23,7 +27,7 @@ static int fail(const char* what) {
 
 int main(int argc, char** argv) {
     int arm = 5, device = 0;
-    bool specialise = false, generic = false;
+    bool specialise = false, generic = false, reference_stream = false, f32 = false, near_far = false;
     long width = -1, height = -1, spp = -1, depth = 50; /* MAX_DEPTH main.rs:801 */
     unsigned long long build_seed = 1, seed = 0;
     std::string out_path, earth_path;
@@ -45,8 +49,11 @@ int main(int argc, char** argv) {
         else if (a == "--out") out_path = next("--out");
         else if (a == "--specialise") specialise = true;
         else if (a == "--generic") generic = true;
+        else if (a == "--reference-stream") reference_stream = true;
+        else if (a == "--f32") f32 = true;
+        else if (a == "--near-far") near_far = true;
         else if (a == "--earth") { earth_path = next("--earth"); earth_w = (unsigned)std::atoi(next("--earth W")); earth_h = (unsigned)std::atoi(next("--earth H")); }
-        else { std::fprintf(stderr, "usage: rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B] [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B] [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic] [--reference-stream] [--f32] [--near-far]\n"); return 2; }
     }
     std::vector<unsigned char> earth;
     if (!earth_path.empty()) {
@@ -69,6 +76,7 @@ int main(int argc, char** argv) {
     if (width <= 0) width = defaults[0];
     if (height <= 0) height = (long)((double)width / aspect); /* main.rs:939 */
     if (spp <= 0) spp = defaults[2];
+    if (near_far && rt1w_scene_set_walk_order(scene, RT1W_WALK_NEAR_FAR) < 0) return fail("walk order");
     rt1w_context* ctx = nullptr;
     if (rt1w_context_create(device, scene, &ctx) < 0) return fail("context");
     if (specialise && !generic) {
@@ -81,6 +89,8 @@ int main(int argc, char** argv) {
     p.width = (uint32_t)width; p.height = (uint32_t)height; p.tile_w = p.width; p.tile_h = p.height;
     p.spp = (uint32_t)spp; p.max_depth = (uint32_t)depth; p.global_seed = (uint32_t)seed;
     if (generic) p.flags |= RT1W_GENERIC;
+    if (reference_stream) p.flags |= RT1W_RNG_REFERENCE;
+    if (f32) p.precision = RT1W_PRECISION_F32;
     /* the reference collects the rows top-down, counting them down on stderr (main.rs:957-960,995-998), then prints them
      * (main.rs:1003-1007); here the rows are quantised on the device and written as their strips land */
     std::vector<unsigned char> img((size_t)width * height * 3);

@@ -652,3 +652,29 @@ def test_f32_mode_matches_the_f64_frame_statistically(rt, gpu_ctx_factory):
         assert abs(y.mean() / x.mean() - 1.0) < 0.03, (arm, x.mean(), y.mean())
     with pytest.raises(rt.Rt1wError):
         ctx.render(64, 64, 4, f32=True, reference_stream=True)
+
+
+def test_cli_with_the_reference_stream_prints_the_reference_programs_output(rt, tmp_path):
+    """`rt1w --reference-stream` with no other option is the reference's `main` as shipped (match 5 -> Cornell, 600x600,
+    100 spp, depth 50; main.rs:815,868-870): its P3 text, parsed back, is rest_of_your_life.png on every pixel -- i.e. the
+    bytes `cargo run` of the reference prints.  Wavefront edge cases ride along: depths below / at the number of
+    wavefront bounces and depth 0 equal the megakernel."""
+    import hashlib, subprocess
+    pix = json.load(open(os.path.join(HERE, "golden", "cornell_png_pixels.json")))
+    exe = os.path.join(orc.ROOT, "raytracing-1w_amd", "rt1w")
+    out = tmp_path / "ref.ppm"
+    subprocess.check_call([exe, "--reference-stream", "--out", str(out)], stderr=subprocess.DEVNULL)
+    tok = out.read_text().split()
+    assert tok[:4] == ["P3", "600", "600", "255"]
+    img = np.array(tok[4:], dtype=np.uint8).reshape(600, 600, 3)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == pix["sha256_rgb_top_down"]
+
+
+def test_wavefront_depth_edge_cases(rt, gpu_ctx_factory):
+    ctx = gpu_ctx_factory(rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5))
+    for depth in (0, 1, 3, 6, 7):
+        a, sa = ctx.render(72, 48, 6, max_depth=depth)
+        b, sb = ctx.render(72, 48, 6, max_depth=depth, wavefront=True)
+        assert (sb["sorted"] & 8) and sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), depth
+    with pytest.raises(rt.Rt1wError):
+        ctx.render(72, 48, 2, max_depth=65, wavefront=True)          # beyond WF_MAX_BOUNCES: refused, not silently different
