@@ -56,7 +56,9 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 #ifdef RT_SORT_WAVES_OVERRIDE /* experiments (RT1W_JIT_EXTRA_OPTS=-DRT_SORT_WAVES_OVERRIDE=4) */
 #define RT_SORT_WAVES(Cfg) RT_SORT_WAVES_OVERRIDE
 #else
-#define RT_SORT_WAVES(Cfg) ((Cfg::sweep && !Cfg::media) ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2) /* waves per SIMD the kernel is built for */
+/* waves per SIMD the kernel is built for: 3 for the media-free sweep variants and for every scene-specialised kernel (the
+ * specialised cornel_smoke kernel sits right at the 168-register step: 169 registers = 2 waves = -22 %, measured) */
+#define RT_SORT_WAVES(Cfg) ((Cfg::sweep && (!Cfg::media || !std::is_void<typename Cfg::Topo>::value)) ? (RT_SORT_BLOCK == 512 ? 2 : 3) : 2)
 #endif
 template <class Cfg>
 __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
