@@ -44,6 +44,7 @@ extern "C" int rt1w_internal_f32_create(const void* nodes, uint32_t n_nodes, con
                                         const void* view64, void** out);
 extern "C" void rt1w_internal_f32_destroy(void* h);
 extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted);
+extern "C" unsigned rt1w_internal_f32_view(void* h, void* out, unsigned cap); /* bytes of the f32 RtSceneView (kernel argument) */
 extern "C" int rt1w_internal_f32_launch(void* h, int variant, int sorted, const void* frame, double* partial, unsigned long long* counters, int grid,
                                         hipStream_t stream);
 
@@ -173,6 +174,12 @@ struct rt1w_context {
     int jit_grid = 0;
     uint32_t jit_vgprs = 0;
     bool jit_failed = false; /* a compile was tried and failed: do not try again on this context */
+    /* the same for RT1W_PRECISION_F32: loaded / compiled at the first f32 render of a specialised context */
+    std::string jit32_src;
+    hipModule_t jit32_mod = nullptr;
+    hipFunction_t jit32_fn = nullptr;
+    int jit32_grid = 0;
+    bool jit32_tried = false;
 };
 
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
@@ -193,6 +200,15 @@ bool upload(void** dst, const void* src, size_t bytes) {
     if (!hip_ok(hipMalloc(dst, alloc), "hipMalloc(scene)")) return false;
     if (bytes && !hip_ok(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(scene)")) return false;
     return true;
+}
+
+/* the node array with one spare (zeroed) record behind it: the fused walk requests record e + 1 together with record e */
+bool upload_nodes(void** dst, const std::vector<RtNode>& nodes) {
+    std::vector<RtNode> padded(nodes);
+    RtNode z;
+    memset(&z, 0, sizeof z);
+    padded.push_back(z);
+    return upload(dst, padded.data(), padded.size() * sizeof(RtNode));
 }
 
 int validate(const rt1w_context* c, const rt1w_render_params* p) {
@@ -263,6 +279,27 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
                 rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
             }
         }
+        /* a context that runs a scene-specialised kernel in f64 gets the f32 build of that kernel too (kernel cache, else hiprtc) */
+        if (c->jit_fn && !c->jit32_tried && !c->jit32_src.empty()) {
+            c->jit32_tried = true;
+            std::vector<char> code;
+            rt1w::JitInfo info;
+            hipFunction_t fn = nullptr;
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            if (rt1w::jit_get_code(c->jit32_src, !getenv("RT1W_NO_JIT"), code, info) >= 0 &&
+                hipModuleLoadData(&c->jit32_mod, code.data()) == hipSuccess &&
+                hipModuleGetFunction(&fn, c->jit32_mod, "rt_jit_sorted") == hipSuccess &&
+                hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_SORT_BLOCK, 0) == hipSuccess &&
+                hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
+                c->jit32_fn = fn;
+                c->jit32_grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+            }
+        }
+        if (c->jit32_fn && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !(p->flags >> 8)) {
+            L.f32 = true; L.jit = true; L.sorted = true; L.cached = false; L.variant = v; L.grid = c->jit32_grid; L.block = RT_SORT_BLOCK;
+            return RT1W_OK;
+        }
         const bool sorted = v < 2 && !(p->flags & RT1W_UNSORTED);
         int& g = c->f32_grid[v][sorted ? 1 : 0];
         if (!g) {
@@ -319,7 +356,15 @@ int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
 int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const RtLaunch& L, double* d_out) {
     hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block);
     (void)hipEventRecord(l.ev0, l.stream);
-    if (L.f32) {
+    if (L.f32 && L.jit) {
+        unsigned char view32[512];
+        if (!c->f32_scene || rt1w_internal_f32_view(c->f32_scene, view32, sizeof view32) == 0u) { rt1w::set_error("single-precision scene missing"); return RT1W_ERR_DEVICE; }
+        RtFrame frame = L.f;
+        double* partial = l.d_partial;
+        unsigned long long* counters = l.d_counters;
+        void* args[] = {view32, &frame, &partial, &counters};
+        if (!hip_ok(hipModuleLaunchKernel(c->jit32_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised f32 kernel launch")) return RT1W_ERR_DEVICE;
+    } else if (L.f32) {
         if (!c->f32_scene || rt1w_internal_f32_launch(c->f32_scene, L.variant, L.sorted ? 1 : 0, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
             rt1w::set_error("single-precision kernel launch failed"); return RT1W_ERR_DEVICE;
         }
@@ -583,7 +628,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     if (!c) { rt1w::set_error("out of memory"); return RT1W_ERR_NOMEM; }
     c->device = device_id;
     bool ok = lane_init(c->lane[0]) &&
-              upload(&c->d_nodes, s->flat_nodes.data(), s->flat_nodes.size() * sizeof(RtNode)) &&
+              upload_nodes(&c->d_nodes, s->flat_nodes) &&
               upload(&c->d_lights, s->flat_lights.data(), s->flat_lights.size() * sizeof(RtNode)) &&
               upload(&c->d_materials, s->materials.data(), s->materials.size() * sizeof(RtMaterial)) &&
               upload(&c->d_textures, s->textures.data(), s->textures.size() * sizeof(RtTexture)) &&
@@ -658,6 +703,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     }
     if (rt1w::jit_eligible(*s)) {
         c->jit_src = rt1w::jit_source(*s);
+        c->jit32_src = rt1w::jit_source(*s, true);
         rt1w::JitInfo info;
         (void)specialise(c, false, info); /* a cache hit is used from the first render on; a miss costs nothing */
     }
@@ -676,6 +722,7 @@ void rt1w_context_destroy(rt1w_context* c) {
     lane_destroy(c->lane[0]);
     lane_destroy(c->lane[1]);
     if (c->jit_mod) (void)hipModuleUnload(c->jit_mod);
+    if (c->jit32_mod) (void)hipModuleUnload(c->jit32_mod);
     if (c->ev_first) (void)hipEventDestroy(c->ev_first);
     delete c;
 }

@@ -112,7 +112,8 @@ extern "C" int rt1w_internal_f32_create(const void* nodes_, uint32_t n_nodes, co
     const ::RtSceneView& v64 = *static_cast<const ::RtSceneView*>(view64_);
     F32Scene* s = new (std::nothrow) F32Scene();
     if (!s) return -1;
-    std::vector<rtf32::RtNode> fn(n_nodes), fl(n_lights);
+    std::vector<rtf32::RtNode> fn(n_nodes + 1u), fl(n_lights); /* + one spare record: the fused walk reads record e + 1 with record e */
+    memset(&fn[n_nodes], 0, sizeof fn[n_nodes]);
     for (uint32_t i = 0; i < n_nodes; ++i) fn[i] = conv_node(nodes[i]);
     for (uint32_t i = 0; i < n_lights; ++i) fl[i] = conv_node(lights[i]);
     std::vector<rtf32::RtMaterial> fm(n_materials);
@@ -149,6 +150,13 @@ extern "C" int rt1w_internal_f32_create(const void* nodes_, uint32_t n_nodes, co
     v.background = v3f(v64.background);
     *out = s;
     return 0;
+}
+
+extern "C" unsigned rt1w_internal_f32_view(void* h, void* out, unsigned cap) {
+    F32Scene* s = static_cast<F32Scene*>(h);
+    if (!s || cap < sizeof s->view) return 0u;
+    memcpy(out, &s->view, sizeof s->view);
+    return (unsigned)sizeof s->view;
 }
 
 extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted) {

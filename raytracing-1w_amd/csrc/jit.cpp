@@ -151,10 +151,14 @@ bool jit_eligible(const rt1w_scene& s) {
     return s.committed && !s.flat_nodes.empty() && s.flat_nodes.size() <= RT_JIT_MAX_NODES;
 }
 
-std::string jit_source(const rt1w_scene& s) {
+std::string jit_source(const rt1w_scene& s, bool f32) {
     const std::vector<RtNode>& N = s.flat_nodes;
     std::string src;
     src += "/* generated by librt1w (jit.cpp) for one scene topology */\n";
+    if (f32) /* the single-precision build of the same kernel: context_f32.hip's switch, here for the run-time compiler */
+        src += "#include <stdint.h>\n#include <type_traits>\ntypedef double rt_f64;\n#define RT_F32 1\n#define double float\n";
+    else
+        src += "#include \"rt1w_num.h\"\n"; /* declares rt_f64 */
     src += "#include \"rt_kernel_sorted.h\"\n";
     src += "struct TopoJit {\n";
     src += "    static constexpr uint32_t n = " + std::to_string(N.size()) + "u, root = " + std::to_string(s.flat_root) + "u;\n";
@@ -169,7 +173,7 @@ std::string jit_source(const rt1w_scene& s) {
     src += std::string("typedef RtCfg<") + (s.has_media ? "true" : "false") + ", " + (s.has_tex ? "true" : "false") + ", " +
            (s.has_msphere ? "true" : "false") + ", true, " + std::to_string(depth) + ", TopoJit> CfgJit;\n";
     src += "extern \"C\" __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(CfgJit)) void rt_jit_sorted(\n"
-           "    RtSceneView sc, RtFrame f, double* __restrict__ partial, unsigned long long* __restrict__ counters) {\n"
+           "    RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {\n"
            "    rt_render_sorted_body<CfgJit>(sc, f, partial, counters);\n}\n";
     return src;
 }
@@ -242,10 +246,10 @@ int jit_get_code(const std::string& src, bool allow_compile, std::vector<char>& 
     return RT1W_OK;
 }
 
-int jit_precompile_to(const rt1w_scene& s, const std::string& dir, JitInfo& info) {
+int jit_precompile_to(const rt1w_scene& s, const std::string& dir, JitInfo& info, bool f32) {
     info = JitInfo();
     if (!jit_eligible(s)) { info.message = "scene is not eligible"; return RT1W_ERR_UNSUPPORTED; }
-    const std::string src = jit_source(s);
+    const std::string src = jit_source(s, f32);
     info.key = jit_key(src);
     const std::string path = dir + "/sweep_" + info.key + ".hsaco";
     std::vector<char> code;

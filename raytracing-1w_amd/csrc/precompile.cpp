@@ -34,6 +34,13 @@ int main(int argc, char** argv) {
                 else keep.insert(info.path.substr(info.path.rfind('/') + 1));
                 if (rc >= 0) std::printf("arm %d seed %llu: %zu nodes -> %s (%s, %.1f s)\n", arm, seed, s->flat_nodes.size(), info.path.c_str(),
                                  info.from_cache ? "present" : "compiled", info.compile_ms / 1e3);
+                if (arm == 5 || arm == 6) { /* the Cornell arms also in single precision (RT1W_PRECISION_F32) */
+                    rt1w::JitInfo i32;
+                    int r32 = rt1w::jit_precompile_to(*s, dir, i32, true);
+                    if (r32 < 0) { std::fprintf(stderr, "arm %d seed %llu (f32): %s\n", arm, seed, i32.message.c_str()); ++failures; }
+                    else { keep.insert(i32.path.substr(i32.path.rfind('/') + 1));
+                           std::printf("arm %d seed %llu f32: -> %s (%s, %.1f s)\n", arm, seed, i32.path.c_str(), i32.from_cache ? "present" : "compiled", i32.compile_ms / 1e3); }
+                }
             }
             rt1w_scene_destroy(s);
         }

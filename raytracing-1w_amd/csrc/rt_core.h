@@ -523,6 +523,107 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root,
     return k.best_prim != RT_NONE;
 }
 
+/* The same walk with fewer steps: the lane keeps its CURRENT node in a register (stepping into the left child costs no stack
+ * traffic), and a box node is visited together with its left child when that is a box too -- the reference tests the left
+ * child immediately after the parent with the same closest hit (bvh.rs:36-39), so doing both in one step changes neither the
+ * order nor any operand.  The left child's record is the next one in memory and is requested with the parent's (the node
+ * array carries one spare record at its end).  The walk is paced by the latency and the bookkeeping of a step, not by the
+ * slab arithmetic (PMC), so fewer, fatter steps pay: 48 -> 33 steps per segment on random_scene. */
+/* RT_WALK_MODE: 0 = the classic loop (every visit is a pop), 1 = current node in a register (stepping into the first child
+ * costs no stack traffic), 2 = 1 + the fused left child.  MEASURED (random_scene / final_scene, Mpaths/s): mode 0 475 / 117,
+ * mode 2 395 / 105 -- the second record costs 16 registers in a kernel that already spills, and its loads compete with the
+ * walk's own; mode 1: see DESIGN section 8.  Exactness of every mode is covered by the CPU tier (the tests build oracle B
+ * with the library's default). */
+#ifndef RT_WALK_MODE
+#define RT_WALK_MODE 0
+#endif
+#define RT_FUSED_WALK (RT_WALK_MODE == 2)
+template <class Cfg, class Stack>
+RT_HD void rt_walk_push_children(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk, uint32_t& first) {
+    /* children of a BVH node whose box was hit: `first` is visited next, the other one (if any) is pushed */
+    first = e + 1u;
+    if ((nd.kind & RT_KIND_MASK) == RT_BVH2) {
+        uint32_t second = nd.b;
+        const uint32_t ord = Cfg::ordered ? (nd.kind >> RT_BVH_ORDER_SHIFT) & RT_BVH_ORDER_MASK : 0u;
+        if (Cfg::ordered && ord != 0u) {
+            const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
+            const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
+            if ((da < 0.0 && left_lower) || (da > 0.0 && !left_lower)) { first = nd.b; second = e + 1u; }
+        }
+        stk.push(second);
+    }
+}
+template <class Cfg, bool EARLY>
+RT_HD bool rt_walk_slab(const RtWalk& k, const RtNodeHot& nd) {
+    if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) return rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+    return rt_aabb_hit_fast<EARLY>(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+}
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD bool rt_traverse_stack_fused(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
+                                   double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim, uint32_t& out_scope) {
+    RtWalk k;
+    k.w.o = world.o; k.w.d = world.d;
+    k.cur = k.w;
+    k.inv_w = rt_inv3(k.w.d);
+    k.inv = k.inv_w;
+    k.time = world.time; k.t_min = t_min; k.best_t = t_max;
+    k.scope = RT_NONE; k.best_prim = RT_NONE; k.best_scope = RT_NONE;
+    k.tmin_nan = rt_isnan(t_min);
+    k.base = stk.sp;
+    uint32_t e = root;
+    for (;;) {
+        bool do_pop = true;
+        if (e & RT_POP_FLAG) {
+            rt_walk_exit(sc, k, e);
+        } else {
+            const RtNodeHot nd = ns.hot(e);
+            const RtNodeHot nl = RT_FUSED_WALK ? ns.hot(e + 1u) : nd; /* the next record in pre-order = the left child of a BVH node */
+            const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
+            RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
+            if (cls == RT_WK_BOX) {
+                if (rt_walk_slab<Cfg, Cfg::media>(k, nd)) {
+                    uint32_t first;
+                    rt_walk_push_children<Cfg>(k, e, nd, stk, first);
+                    const bool left_first = first == e + 1u;
+                    e = first;
+                    do_pop = false;
+                    /* the left child in the same step when it is a box too (same closest hit: nothing happened in between) */
+                    if (RT_FUSED_WALK && left_first && rt_walk_class(nl.kind & RT_KIND_MASK) == RT_WK_BOX) {
+                        RT_STAT_VISIT(nl.kind & RT_KIND_MASK);
+                        if (rt_walk_slab<Cfg, Cfg::media>(k, nl)) {
+                            uint32_t f2;
+                            rt_walk_push_children<Cfg>(k, e, nl, stk, f2);
+                            e = f2;
+                        } else {
+                            do_pop = true;
+                        }
+                    }
+                }
+            } else if (cls == RT_WK_LEAF) {
+                rt_walk_leaf<Cfg>(sc, k, e, nd);
+            } else if (cls == RT_WK_WRAP) {
+                const uint32_t kind = nd.kind & RT_KIND_MASK;
+                stk.push(e | RT_POP_FLAG);
+                k.scope = e;
+                if (kind != RT_FLIP) {
+                    k.cur = rt_scope_in(nd, k.cur);
+                    if (kind == RT_ROTATE_Y) k.inv = rt_inv3(k.cur.d);
+                }
+                e = e + 1u;
+                do_pop = false;
+            } else {
+                rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
+            }
+        }
+        if (do_pop) {
+            if (stk.sp <= k.base) break;
+            e = stk.pop();
+        }
+    }
+    out_t = k.best_t; out_prim = k.best_prim; out_scope = k.best_scope;
+    return k.best_prim != RT_NONE;
+}
+
 /* The same traversal without a stack, for small scenes.  Nodes are stored in
  * depth-first pre-order and every node knows where its subtree ends (`skip`), so
  * the reference's walk (left subtree, then right subtree) is "visit node n, then
@@ -700,6 +801,7 @@ RT_HD bool rt_closest_hit(const RtSceneView& sc, const NS& ns, const RtRay& ray,
         scope = prim == RT_NONE ? RT_NONE : ns.hot(prim).b; /* leaves keep their innermost wrapper in `b` */
         return prim != RT_NONE;
     } else if constexpr (Cfg::sweep) return rt_traverse_sweep<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, t, prim, scope);
+    else if constexpr (RT_WALK_MODE != 0) return rt_traverse_stack_fused<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
     else return rt_traverse_stack<Cfg, true>(sc, ns, sc.root, ray, t_min, t_max, rng, stk, t, prim, scope);
 }
 

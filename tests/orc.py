@@ -158,6 +158,7 @@ def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offse
     if chunk == 0:
         chunk = rt().default_chunk(tw, th, spp)
     arrs = [scene.flat(i) for i in range(7)]
+    arrs[0] = np.concatenate([arrs[0], np.zeros(96, dtype=np.uint8)])   # one spare record: the fused walk reads record e + 1 with record e
     info = scene.info()
     if variant is None:
         variant = info["variant"]

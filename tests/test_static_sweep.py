@@ -46,7 +46,7 @@ def static_lib(rt, tmp_path_factory):
                    f"  static constexpr uint32_t skip[{n}] = {{{', '.join(str(int(x)) + 'u' for x in nodes['skip'])}}}; }};\n"
                    f"typedef RtCfg<{'true' if info['has_media'] else 'false'}, {'true' if info['has_textures'] else 'false'}, "
                    f"{'true' if info['has_moving'] else 'false'}, true, {max(2, info['scope_depth'])}, Topo{k}> CfgS{k};\n")
-        sw.append(f"case {100 + k}: run_path<CfgS{k}>(sc, f, px, py, s, stk, sum, segs); break;")
+        sw.append(f"case {100 + k}: run_path<CfgS{k}>(sc, f, px, py, s, stk, sum, segs, path); break;")
     (work / "topo_gen.h").write_text("".join(hdr) + f"#define ORC_N_STATIC {len(cases)}\n#define ORC_STATIC_CASES " + " ".join(sw) + "\n")
     so = work / "liborc_flat_static.so"
     cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unknown-pragmas",
