@@ -245,6 +245,7 @@ def main():
                        "parallelism": (f"image-tiled x{world}: 16-row strips round-robin, one launch per GPU, every GPU's D2H writes its "
                                        f"strips into one shared pinned host frame (host gather, no collective)") if world > 1
                                       else "1 GPU, D2H into a pinned host frame",
+                       "host_frame_pinned": bool(frame._pinned) if frame is not None else True,
                        "commit": git_head()},
             "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -67,12 +67,18 @@ class SharedFrame:
         self._rt = rt
         self._pinned = False
         if rt is not None:
-            rt.host_register(self.array)
-            self._pinned = True
+            try:   # pinning is an optimisation (full-rate, asynchronous device->host copies); a pageable frame works too
+                rt.host_register(self.array)
+                self._pinned = True
+            except Exception:
+                self._pinned = False
 
     def close(self):
         if self._pinned:
-            self._rt.host_unregister(self.array)
+            try:
+                self._rt.host_unregister(self.array)
+            except Exception:
+                pass
             self._pinned = False
         self.array = None
         try:

@@ -568,6 +568,9 @@ def test_c5_full_size_3840x2160_10000spp(rt, gpu_ctx_factory):
         assert np.array_equal(full[y0:y0 + h, x0:x0 + w], b)
     one, _ = ctx.render(W, H, spp, tile=(0, 1072, W, 16), chunk=chunk)
     assert np.array_equal(one, full[1072:1088])
+    # the ONE-SHOT entry on the same job: 20 chunks x 8.3 M pixels x 24 B = 4 GB of chunk partial sums in one launch
+    whole, sw = ctx.render(W, H, spp)
+    assert sw["n_chunks"] * W * H * 24 > 3.9e9 and sw["segments"] == st["segments"] and np.array_equal(whole, full)
     print(f"C5 full size: {st['total_ms'] / 1e3:.1f} s, {st['paths'] / st['total_ms'] / 1e3:.0f} Mpaths/s incl. D2H, "
           f"{st['segments'] / st['paths']:.3f} segments/path")
 
