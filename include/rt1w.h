@@ -160,7 +160,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
 #define RT1W_GENERIC 8u   /* do not use a scene-specialised kernel even if the context has one (rt1w_context_specialise) */
-#define RT1W_WAVEFRONT 16u /* experiment, big scenes (stack-walk variants) only: path state queued in HBM, trace and shade as separate kernels per bounce; bit-identical, measured 0.45-0.7x the default */
+#define RT1W_WAVEFRONT 16u /* opt-in, big scenes (stack-walk variants) and the one-shot entries only: path state queued in HBM as SoA records, a vote-scheduled trace kernel + a shade kernel per bounce, a finish kernel for the tail (rt_wavefront.h); bit-identical to the default, measured 0.7-0.8x its speed.  Scenes that run a sweep kernel ignore the flag (stats.sorted bit 3 says what ran); rt1w_render_rows refuses it */
 #define RT1W_OUT_FRAME 32u /* rt1w_render only: `out_rgb` is the WHOLE image [height][width][3] (row 0 = j = 0) and the call writes just its tile's pixels at their image positions -- several contexts / processes fill one (shared, pinned) host frame: the host gather of the image-tiled multi-GPU job */
 #define RT1W_RNG_REFERENCE 64u /* PARITY MODE: draw from the reference's own generator instead of the Philox streams -- `StdRng::seed_from_u64(j * image_width + i)` (src/main.rs:964; ChaCha12, rand 0.8.4), one stream per pixel drawn on through all its samples in order (sample_offset must be 0, global_seed is ignored).  The frame is then the Rust program's own, pixel for pixel: the GPU reproduces rest_of_your_life.png.  Slower than the default (a lane owns a pixel for all its samples) */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering) */
@@ -197,8 +197,11 @@ typedef struct rt1w_stats {
     double total_ms;       /* host wall time of the call incl. device->host copy */
     uint32_t chunk, n_chunks;
     uint32_t grid, block;
-    uint32_t variant;      /* kernel variant used (V0..V3) */
-    uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: LDS node cache */
+    uint32_t variant;      /* feature variant of the kernel (V0..V4: rt_flat.h).  With bit 2 of `sorted` set the kernel that ran is the
+                              scene-specialised SWEEP kernel whatever walk this number names (scenes of 65-256 nodes report a stack
+                              variant here because that is what the generic code would have used) */
+    uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: node records in LDS; bit 2: scene-specialised kernel; bit 3:
+                              wavefront form; bit 4: reference-stream kernel (RT1W_RNG_REFERENCE); bit 5: f32 kernel */
 } rt1w_stats;
 
 /* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */

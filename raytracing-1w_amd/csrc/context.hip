@@ -790,6 +790,7 @@ int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t stri
     if (format != RT1W_ROWS_F64 && format != RT1W_ROWS_U8) { rt1w::set_error("unknown output format"); return RT1W_ERR_INVALID; }
     if (format == RT1W_ROWS_U8 && (p->flags & RT1W_OUT_SUM)) { rt1w::set_error("RT1W_OUT_SUM has no 8-bit form"); return RT1W_ERR_INVALID; }
     if ((p->flags & RT1W_OUT_FRAME) || p->strip_rows) { rt1w::set_error("rt1w_render_rows takes contiguous tiles only"); return RT1W_ERR_INVALID; }
+    if (p->flags & RT1W_WAVEFRONT) { rt1w::set_error("rt1w_render_rows runs the persistent kernels only (RT1W_WAVEFRONT is a one-shot form)"); return RT1W_ERR_UNSUPPORTED; }
     if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t H = p->tile_h, W = p->tile_w;
