@@ -23,6 +23,10 @@
  * visits (the vote only decides WHEN a lane's next visit happens), same generator stream (the buffered block is dropped
  * at a hand-over and regenerated: same words) -- and a pixel's samples are summed in sample order per chunk
  * (wf_chunk_sum), so the frame is bit-identical to the megakernel's (tests/test_gpu_parity.py).
+ * MEASURED (profiles/r02_wavefront_*): the trace kernel reaches the model's lane utilisation (59 % / 52 % against the
+ * megakernel's 24 % / 9 %) with a VALU that is 38 % / 27 % busy -- the walk is paced by the latency and bookkeeping of a
+ * step, which the model does not price -- and the whole form ends at 0.7-0.8x the megakernel (random_scene 384 vs 474,
+ * final_scene 119 vs 116 Mpaths/s at 16-24 spp; 379 vs 542 and 116 vs 157 at 100 spp).  Opt-in, not the default.
  */
 #ifndef RT_WAVEFRONT_H
 #define RT_WAVEFRONT_H
