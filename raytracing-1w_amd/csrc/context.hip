@@ -679,7 +679,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
                                  s->perlin.data(), (uint32_t)s->perlin.size(), &c->view, &c->f32_scene) != 0) {
         rt1w::set_error("could not build the single-precision scene arrays"); rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
     }
-    if (c->variant >= 2) {
+    {
         /* walk records for the wavefront form: eligible when every MovingSphere has the same (time0, time1) */
         std::vector<WfRec> recs(s->flat_nodes.size());
         bool ok_ms = true, seen = false;

@@ -38,6 +38,7 @@ def test_random_scene_graph_flat_core_vs_literal_oracle(rt, seed):
 def test_random_scene_graphs_on_the_gpu(rt, gpu_ctx_factory):
     """The same random graphs through the HIP kernels (default kernel, plain kernel, every valid forced variant):
     bit-identical to the CPU build of the core, equal segment counts, and within 1e-12 of the literal oracle."""
+    n_wavefront = 0
     for seed in range(16):
         prod, oracle = random_scene_pair(2000 + seed)
         info = prod.info()
@@ -53,4 +54,20 @@ def test_random_scene_graphs_on_the_gpu(rt, gpu_ctx_factory):
         for v in (1, 3):
             f, sf = ctx.render(W, H, spp, variant=v)
             assert np.array_equal(f, g, equal_nan=True), (seed, v)
+        # the wavefront form on the same graphs (forced stack-walk variant: wrappers, media, nested BVHs through the
+        # vote-scheduled trace kernel with LDS-resident walk records, the shade kernel and the finish kernel)
+        try:
+            w, sw = ctx.render(W, H, spp, variant=3, wavefront=True)
+            assert (sw["sorted"] & 8) and sw["segments"] == sg["segments"] and np.array_equal(w, g, equal_nan=True), (seed, "wavefront")
+            n_wavefront += 1
+        except rt.Rt1wError as e:                  # graphs whose moving spheres have different shutter intervals keep the megakernel
+            assert e.code == rt.ERR_UNSUPPORTED and "shutter" in str(e), e
+        # the reference-stream kernels against the CPU build of the same core with the same switch
+        r, sr = ctx.render(W, H, spp, reference_stream=True)
+        c, sc_ = orc.flat_render(prod, W, H, spp, chunk=spp, lib=orc.flat_ref_lib(), variant=1 if info["n_nodes"] <= 64 else 3)
+        assert sr["segments"] == sc_["segments"] and np.array_equal(r, c, equal_nan=True), (seed, "reference stream")
+        # f32: renders, finite where the f64 frame is, and close in the mean
+        h, sh = ctx.render(W, H, spp, f32=True)
+        assert (sh["sorted"] & 32) and abs(np.nanmean(h) - np.nanmean(g)) <= 0.05 * abs(np.nanmean(g)) + 1e-3, (seed, "f32")
         ctx.close()
+    assert n_wavefront >= 8
