@@ -11,8 +11,8 @@ device->host gather; scene build/upload and PPM text excluded).  The scene and c
          its strips straight into ONE shared pinned host frame (sharding.SharedFrame) -- the host gather, inside the
          timed region.  No data-path collective; ranks share a barrier and a max-reduce of the elapsed time (gloo).
          Weak scaling (task rule: independent units sharded across ranks): the frame grows with N at constant 1000 spp
-         and constant camera -- side = 8*round(600*sqrt(N)/8): 600, 848, 1200, 1696 -- so every GPU keeps C3's 3.6e8
-         paths per step and the per-pixel cost distribution of the Cornell view.  --strong keeps C3's 600x600 for all N.
+         and constant camera -- side = 16N*round(600*sqrt(N)/16N): 600, 832, 1216, 1664, a whole number of 16-row strips per GPU --
+         so every GPU keeps C3's 3.6e8 paths per step within 4 % and the per-pixel cost distribution of the Cornell view.  --strong keeps C3's 600x600 for all N.
          --workload c5 is BASELINE config C5 (3840x2160, 16:9) at --spp (default 1000; 10 000 takes 22 s per step per GPU).
 
 `value` = whole-job paths / s over the timed steps, copy included.  The device-resident rate (framebuffer left in HBM)
@@ -120,7 +120,9 @@ def main():
         if world > 1 and not a.strong:
             a.strong = True                                              # C5 is one fixed frame
     else:
-        side = C3_W if (a.strong or world == 1) else 8 * round(C3_W * math.sqrt(world) / 8)
+        # weak scaling: ~C3's paths per GPU, and a side that is a multiple of 16 * N rows so that every GPU owns the same number of
+        # 16-row strips (N = 2, 4, 8: 832, 1216, 1664)
+        side = C3_W if (a.strong or world == 1) else 16 * world * max(1, round(C3_W * math.sqrt(world) / (16 * world)))
         W, H, aspect, name = side, side, 1.0, "C3 cornel_box"
     spp = a.spp
     scene = rt.Scene.reference(5, build_seed=1, aspect_ratio=aspect)
