@@ -11,7 +11,7 @@ device->host gather; scene build/upload and PPM text excluded).  The scene and c
          its strips straight into ONE shared pinned host frame (sharding.SharedFrame) -- the host gather, inside the
          timed region.  No data-path collective; ranks share a barrier and a max-reduce of the elapsed time (gloo).
          Weak scaling (task rule: independent units sharded across ranks): the frame grows with N at constant 1000 spp
-         and constant camera -- side = 16N*round(600*sqrt(N)/16N): 600, 832, 1216, 1664, a whole number of 16-row strips per GPU --
+         and constant camera -- side = 16N*round(600*sqrt(N)/16N): 600, 864, 1216, 1664, a whole number of 16-row strips per GPU --
          so every GPU keeps C3's 3.6e8 paths per step within 4 % and the per-pixel cost distribution of the Cornell view.  --strong keeps C3's 600x600 for all N.
          --workload c5 is BASELINE config C5 (3840x2160, 16:9) at --spp (default 1000; 10 000 takes 22 s per step per GPU).
 
@@ -121,7 +121,7 @@ def main():
             a.strong = True                                              # C5 is one fixed frame
     else:
         # weak scaling: ~C3's paths per GPU, and a side that is a multiple of 16 * N rows so that every GPU owns the same number of
-        # 16-row strips (N = 2, 4, 8: 832, 1216, 1664)
+        # 16-row strips (N = 2, 4, 8: 864, 1216, 1664)
         side = C3_W if (a.strong or world == 1) else 16 * world * max(1, round(C3_W * math.sqrt(world) / (16 * world)))
         W, H, aspect, name = side, side, 1.0, "C3 cornel_box"
     spp = a.spp
