@@ -134,6 +134,19 @@ int rt1w_scene_build_reference(int arm, uint64_t build_seed, double aspect_ratio
 #define RT1W_WALK_NEAR_FAR_ALL 2u
 int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode);
 
+/* OPT-IN build of the BVHs.  Default RT1W_BVH_REFERENCE: `BVHNode::new` as written -- a random axis per
+ * node, objects sorted by their box minimum on it, split at the median (src/bvh.rs:84-100).  RT1W_BVH_SAH rebuilds the tree
+ * over every BVH's leaf set by the surface-area heuristic (each split minimises area(L)*|L| + area(R)*|R| over the three axes
+ * and every position of the centroid order; boxes are still `surrounding_box` of the children, src/aabb.rs:42-55): fewer
+ * node visits per ray.  The closest hit of a ray does not depend on the tree, but everything that depends on the ORDER of the
+ * walk does -- ties in t, the random numbers a ConstantMedium draws while visited, MovingSphere tests of scattered rays
+ * (see rt1w_scene_set_walk_order) -- so frames are the reference's only statistically, never bit for bit in general
+ * (measured: DESIGN.md section 5).  Combine with RT1W_WALK_NEAR_FAR* freely.  Call on a committed scene, before creating
+ * contexts; RT1W_ERR_UNSUPPORTED (scene unchanged) if the rebuilt trees need a deeper traversal stack than the kernels have. */
+#define RT1W_BVH_REFERENCE 0u
+#define RT1W_BVH_SAH 1u
+int rt1w_scene_set_bvh_build(rt1w_scene* s, uint32_t mode);
+
 /* introspection of the committed flat scene (tests, DESIGN.md numbers) */
 typedef struct rt1w_scene_info {
     uint32_t n_nodes, n_lights, n_materials, n_textures, n_perlin;

@@ -117,6 +117,7 @@ _sig("rt1w_scene_commit", C.c_int, _P)
 _sig("rt1w_scene_build_reference", C.c_int, C.c_int, C.c_uint64, C.c_double, _P, C.c_uint32, C.c_uint32,
      C.POINTER(_P), C.POINTER(C.c_uint32 * 3))
 _sig("rt1w_scene_set_walk_order", C.c_int, _P, C.c_uint32)
+_sig("rt1w_scene_set_bvh_build", C.c_int, _P, C.c_uint32)
 _sig("rt1w_scene_get_info", C.c_int, _P, C.POINTER(SceneInfo))
 _sig("rt1w_scene_copy_flat", C.c_int64, _P, C.c_int, _P, C.c_uint64)
 _sig("rt1w_device_count", C.c_int)
@@ -291,6 +292,12 @@ class Scene:
                                        aperture, focus_dist, time0, time1))
 
     def commit(self): _ck(_lib.rt1w_scene_commit(self._h))
+
+    def set_bvh_build(self, sah):
+        """Opt-in BVH build (rt1w_scene_set_bvh_build): False = BVHNode::new as written (random axis, median split; default),
+        True = the trees rebuilt by surface-area heuristic (statistically the same frames, not bit for bit).  Returns self."""
+        _ck(_lib.rt1w_scene_set_bvh_build(self._h, 1 if sah else 0))
+        return self
 
     def set_walk_order(self, near_far):
         """Opt-in traversal order (rt1w_scene_set_walk_order): False = the reference's left-then-right (default),

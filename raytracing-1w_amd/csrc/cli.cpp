@@ -5,10 +5,10 @@
  * values as defaults.
  *   rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B]
  *        [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic]
- *        [--reference-stream] [--f32] [--near-far]
+ *        [--reference-stream] [--f32] [--near-far] [--sah]
  * --reference-stream draws from the reference's own StdRng per pixel (RT1W_RNG_REFERENCE): `rt1w --reference-stream` prints
  * what `cargo run` of the reference prints, byte for byte (Cornell arm, 600x600, 100 spp).  --f32: RT1W_PRECISION_F32.
- * --near-far: rt1w_scene_set_walk_order(RT1W_WALK_NEAR_FAR).
+ * --near-far: rt1w_scene_set_walk_order(RT1W_WALK_NEAR_FAR).  --sah: rt1w_scene_set_bvh_build(RT1W_BVH_SAH).
  * --specialise compiles the kernel for this scene's topology now if the kernel cache has none (rt1w_context_specialise;
  * by default only a cached kernel is used, and renders of >= 2^35 paths compile on their own); --generic forbids it.
  */
@@ -27,7 +27,7 @@ static int fail(const char* what) {
 
 int main(int argc, char** argv) {
     int arm = 5, device = 0;
-    bool specialise = false, generic = false, reference_stream = false, f32 = false, near_far = false;
+    bool specialise = false, generic = false, reference_stream = false, f32 = false, near_far = false, sah = false;
     long width = -1, height = -1, spp = -1, depth = 50; /* MAX_DEPTH main.rs:801 */
     unsigned long long build_seed = 1, seed = 0;
     std::string out_path, earth_path;
@@ -52,8 +52,9 @@ int main(int argc, char** argv) {
         else if (a == "--reference-stream") reference_stream = true;
         else if (a == "--f32") f32 = true;
         else if (a == "--near-far") near_far = true;
+        else if (a == "--sah") sah = true;
         else if (a == "--earth") { earth_path = next("--earth"); earth_w = (unsigned)std::atoi(next("--earth W")); earth_h = (unsigned)std::atoi(next("--earth H")); }
-        else { std::fprintf(stderr, "usage: rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B] [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic] [--reference-stream] [--f32] [--near-far]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rt1w [--scene N] [--width W] [--height H] [--spp S] [--depth D] [--seed G] [--build-seed B] [--device I] [--earth file.rgb8 W H] [--out file.ppm] [--specialise | --generic] [--reference-stream] [--f32] [--near-far] [--sah]\n"); return 2; }
     }
     std::vector<unsigned char> earth;
     if (!earth_path.empty()) {
@@ -76,6 +77,7 @@ int main(int argc, char** argv) {
     if (width <= 0) width = defaults[0];
     if (height <= 0) height = (long)((double)width / aspect); /* main.rs:939 */
     if (spp <= 0) spp = defaults[2];
+    if (sah && rt1w_scene_set_bvh_build(scene, RT1W_BVH_SAH) < 0) return fail("BVH build");
     if (near_far && rt1w_scene_set_walk_order(scene, RT1W_WALK_NEAR_FAR) < 0) return fail("walk order");
     rt1w_context* ctx = nullptr;
     if (rt1w_context_create(device, scene, &ctx) < 0) return fail("context");

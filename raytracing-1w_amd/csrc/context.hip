@@ -673,7 +673,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->n_nodes = (uint32_t)s->flat_nodes.size();
     c->scope_depth = s->scope_depth;
     c->stack_need = s->stack_need;
-    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth, s->walk_order != 0u);
+    c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth, s->walk_annotated != 0u);
     if (rt1w_internal_f32_create(s->flat_nodes.data(), (uint32_t)s->flat_nodes.size(), s->flat_lights.data(), (uint32_t)s->flat_lights.size(),
                                  s->materials.data(), (uint32_t)s->materials.size(), s->textures.data(), (uint32_t)s->textures.size(),
                                  s->perlin.data(), (uint32_t)s->perlin.size(), &c->view, &c->f32_scene) != 0) {

@@ -50,6 +50,10 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
  * (a path is a pure function of its state; a pixel chunk's samples still run one after the other
  * and are summed in order), so the framebuffer is bit-identical to the unsorted kernel's. */
 #define RT_XCH_QW 26 /* qwords of per-path state exchanged */
+#ifndef RT_XCH_PARTS
+#define RT_XCH_PARTS 1 /* rounds the exchange is done in (LDS per workgroup = ceil(26 / parts) qwords x paths) */
+#endif
+#define RT_XCH_PER ((RT_XCH_QW + RT_XCH_PARTS - 1) / RT_XCH_PARTS)
 #ifndef RT_SORT_BLOCK
 #define RT_SORT_BLOCK 256 /* paths sorted together = workgroup size of the reordering kernel */
 #endif
@@ -65,7 +69,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
                                                       unsigned long long* __restrict__ counters) {
     constexpr int NW = RT_SORT_BLOCK / 64;
     static_assert(Cfg::sweep, "the reordering kernel is built for the stackless variants");
-    __shared__ unsigned long long xch[RT_XCH_QW * RT_SORT_BLOCK];
+    __shared__ unsigned long long xch[RT_XCH_PER * RT_SORT_BLOCK];
     __shared__ uint32_t cnt[NW][RT_N_CLS];
     LdsStack stk;
     stk.base = nullptr;
@@ -158,54 +162,51 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
         }
         if (idle_total == RT_SORT_BLOCK) break; /* every path of the workgroup is done (uniform) */
         {
-            unsigned long long* q = xch + dest;
-#define RT_PUT64(x) do { *q = (x); q += RT_SORT_BLOCK; } while (0)
-#define RT_PUTD(x) RT_PUT64(rt_d2u(x))
-#define RT_PUT2(a, b) RT_PUT64(((unsigned long long)(b) << 32) | (unsigned long long)(uint32_t)(a))
-            RT_PUTD(path.ray.o.x); RT_PUTD(path.ray.o.y); RT_PUTD(path.ray.o.z);
-            RT_PUTD(path.ray.d.x); RT_PUTD(path.ray.d.y); RT_PUTD(path.ray.d.z);
-            RT_PUTD(path.ray.time);
-            RT_PUTD(path.beta.x); RT_PUTD(path.beta.y); RT_PUTD(path.beta.z);
-            RT_PUTD(sum.x); RT_PUTD(sum.y); RT_PUTD(sum.z);
-            RT_PUTD(tr.t);
-            RT_PUT2(path.rng.k0, path.rng.k1); RT_PUT2(path.rng.c1, path.rng.blk);
-            RT_PUT2(path.rng.left, path.rng.bv); RT_PUT2(path.rng.a0, path.rng.a1);
-            RT_PUT2(path.rng.a2, path.rng.a3); RT_PUT2(path.rng.b0, path.rng.b1);
-            RT_PUT2(path.rng.b2, path.rng.b3);
-            RT_PUT2(tr.prim, tr.scope); RT_PUT2(tr.cls, path.depth_left);
-            RT_PUT2(px, py); RT_PUT2(chunk, s);
-            RT_PUT2((have ? 1u : 0u) | (retired ? 2u : 0u) | (path.alive ? 4u : 0u), 0u);
-#undef RT_PUT64
-#undef RT_PUTD
-#undef RT_PUT2
-        }
-        RT_STAMP(10);
-        __syncthreads();
-        RT_STAMP(11);
-        {
-            const unsigned long long* q = xch + threadIdx.x;
-            unsigned long long v_;
-#define RT_GET64() (v_ = *q, q += RT_SORT_BLOCK, v_)
-#define RT_GETD(x) (x) = rt_u2d(RT_GET64())
-#define RT_GET2(a, b) do { unsigned long long t_ = RT_GET64(); (a) = (uint32_t)t_; (b) = (uint32_t)(t_ >> 32); } while (0)
-            RT_GETD(path.ray.o.x); RT_GETD(path.ray.o.y); RT_GETD(path.ray.o.z);
-            RT_GETD(path.ray.d.x); RT_GETD(path.ray.d.y); RT_GETD(path.ray.d.z);
-            RT_GETD(path.ray.time);
-            RT_GETD(path.beta.x); RT_GETD(path.beta.y); RT_GETD(path.beta.z);
-            RT_GETD(sum.x); RT_GETD(sum.y); RT_GETD(sum.z);
-            RT_GETD(tr.t);
-            RT_GET2(path.rng.k0, path.rng.k1); RT_GET2(path.rng.c1, path.rng.blk);
-            RT_GET2(path.rng.left, path.rng.bv); RT_GET2(path.rng.a0, path.rng.a1);
-            RT_GET2(path.rng.a2, path.rng.a3); RT_GET2(path.rng.b0, path.rng.b1);
-            RT_GET2(path.rng.b2, path.rng.b3);
-            RT_GET2(tr.prim, tr.scope); RT_GET2(tr.cls, path.depth_left);
-            RT_GET2(px, py); RT_GET2(chunk, s);
-            uint32_t flags, zero_;
-            RT_GET2(flags, zero_);
+            /* the path state as 26 qwords (compile-time indices only: these stay registers), handed over in RT_XCH_PARTS rounds
+             * through an exchange buffer of ceil(26 / parts) qwords per slot */
+            unsigned long long st[RT_XCH_QW];
+#define RT_PK2(a, b) (((unsigned long long)(b) << 32) | (unsigned long long)(uint32_t)(a))
+            st[0] = rt_d2u(path.ray.o.x); st[1] = rt_d2u(path.ray.o.y); st[2] = rt_d2u(path.ray.o.z);
+            st[3] = rt_d2u(path.ray.d.x); st[4] = rt_d2u(path.ray.d.y); st[5] = rt_d2u(path.ray.d.z);
+            st[6] = rt_d2u(path.ray.time);
+            st[7] = rt_d2u(path.beta.x); st[8] = rt_d2u(path.beta.y); st[9] = rt_d2u(path.beta.z);
+            st[10] = rt_d2u(sum.x); st[11] = rt_d2u(sum.y); st[12] = rt_d2u(sum.z);
+            st[13] = rt_d2u(tr.t);
+            st[14] = RT_PK2(path.rng.k0, path.rng.k1); st[15] = RT_PK2(path.rng.c1, path.rng.blk);
+            st[16] = RT_PK2(path.rng.left, path.rng.bv); st[17] = RT_PK2(path.rng.a0, path.rng.a1);
+            st[18] = RT_PK2(path.rng.a2, path.rng.a3); st[19] = RT_PK2(path.rng.b0, path.rng.b1);
+            st[20] = RT_PK2(path.rng.b2, path.rng.b3);
+            st[21] = RT_PK2(tr.prim, tr.scope); st[22] = RT_PK2(tr.cls, path.depth_left);
+            st[23] = RT_PK2(px, py); st[24] = RT_PK2(chunk, s);
+            st[25] = RT_PK2((have ? 1u : 0u) | (retired ? 2u : 0u) | (path.alive ? 4u : 0u), 0u);
+#undef RT_PK2
+#pragma unroll
+            for (int part = 0; part < RT_XCH_PARTS; ++part) {
+                if (part) __syncthreads(); /* the previous round's readers are done with the buffer */
+#pragma unroll
+                for (int i = part * RT_XCH_PER; i < (part + 1) * RT_XCH_PER && i < RT_XCH_QW; ++i) xch[(i - part * RT_XCH_PER) * RT_SORT_BLOCK + dest] = st[i];
+                RT_STAMP(10);
+                __syncthreads();
+                RT_STAMP(11);
+#pragma unroll
+                for (int i = part * RT_XCH_PER; i < (part + 1) * RT_XCH_PER && i < RT_XCH_QW; ++i) st[i] = xch[(i - part * RT_XCH_PER) * RT_SORT_BLOCK + threadIdx.x];
+            }
+#define RT_UP2(v, a, b) do { (a) = (uint32_t)(v); (b) = (uint32_t)((v) >> 32); } while (0)
+            path.ray.o.x = rt_u2d(st[0]); path.ray.o.y = rt_u2d(st[1]); path.ray.o.z = rt_u2d(st[2]);
+            path.ray.d.x = rt_u2d(st[3]); path.ray.d.y = rt_u2d(st[4]); path.ray.d.z = rt_u2d(st[5]);
+            path.ray.time = rt_u2d(st[6]);
+            path.beta.x = rt_u2d(st[7]); path.beta.y = rt_u2d(st[8]); path.beta.z = rt_u2d(st[9]);
+            sum.x = rt_u2d(st[10]); sum.y = rt_u2d(st[11]); sum.z = rt_u2d(st[12]);
+            tr.t = rt_u2d(st[13]);
+            RT_UP2(st[14], path.rng.k0, path.rng.k1); RT_UP2(st[15], path.rng.c1, path.rng.blk);
+            RT_UP2(st[16], path.rng.left, path.rng.bv); RT_UP2(st[17], path.rng.a0, path.rng.a1);
+            RT_UP2(st[18], path.rng.a2, path.rng.a3); RT_UP2(st[19], path.rng.b0, path.rng.b1);
+            RT_UP2(st[20], path.rng.b2, path.rng.b3);
+            RT_UP2(st[21], tr.prim, tr.scope); RT_UP2(st[22], tr.cls, path.depth_left);
+            RT_UP2(st[23], px, py); RT_UP2(st[24], chunk, s);
+            const uint32_t flags = (uint32_t)st[25];
             have = (flags & 1u) != 0u; retired = (flags & 2u) != 0u; path.alive = (flags & 4u) != 0u;
-#undef RT_GET64
-#undef RT_GETD
-#undef RT_GET2
+#undef RT_UP2
         }
         RT_STAMP(7);
         /* 4. shading (coherent within a wave after the sort) */

@@ -79,6 +79,7 @@ static int bvh_new(rt1w_scene& s, std::vector<int> objects, double time0, double
     HostHittable node;
     node.kind = H_BVH;
     node.has_box = true;
+    node.d[0] = time0; node.d[1] = time1; /* kept for the opt-in rebuild (rt1w_scene_set_bvh_build) */
     if (len == 1) {
         int obj = objects.back();
         if (!bounding_box(s, obj, time0, time1, node.box)) {
@@ -142,6 +143,73 @@ struct Flattener {
     }
     void fail(int code, const char* msg) { if (ok) { ok = false; err = code; set_error(msg); } }
 
+    /* ---- opt-in SAH rebuild (the reference's build is the random-axis median split of bvh.rs:84-100) ----
+     * Same leaf set, same box arithmetic (surrounding_box of the children), another tree: every split minimises
+     * area(L)*|L| + area(R)*|R| over the three axes and all positions of the centroid order. */
+    struct SahItem { int id; AABB box; RtV3 c; };
+    bool collect_leaves(int id, double time0, double time1, std::vector<SahItem>& items) {
+        const HostHittable& h = s.hittables[id];
+        if (h.kind == H_BVH) {
+            if (!collect_leaves(h.left, time0, time1, items)) return false;
+            return h.right < 0 || collect_leaves(h.right, time0, time1, items);
+        }
+        SahItem it;
+        it.id = id;
+        if (!bounding_box(s, id, time0, time1, it.box)) return false;
+        it.c = 0.5 * (it.box.minimum + it.box.maximum);
+        items.push_back(it);
+        return true;
+    }
+    static double half_area(const AABB& b) {
+        const RtV3 e = b.maximum - b.minimum;
+        return e.x * e.y + e.y * e.z + e.z * e.x;
+    }
+    /* reorders items[lo, hi) and returns mid: left = [lo, mid), right = [mid, hi) */
+    static size_t sah_split(std::vector<SahItem>& items, size_t lo, size_t hi) {
+        const size_t n = hi - lo;
+        double best = RT_INF;
+        size_t best_i = n / 2;
+        std::vector<SahItem> best_order;
+        std::vector<SahItem> v(items.begin() + (long)lo, items.begin() + (long)hi);
+        std::vector<double> right_area(n + 1, 0.0);
+        for (int axis = 0; axis < 3; ++axis) {
+            std::stable_sort(v.begin(), v.end(), [axis](const SahItem& a, const SahItem& b) { return rt_get(a.c, axis) < rt_get(b.c, axis); });
+            AABB acc = v[n - 1].box;
+            for (size_t i = n - 1; i >= 1; --i) {
+                acc = (i == n - 1) ? v[i].box : surrounding_box(v[i].box, acc);
+                right_area[i] = half_area(acc);
+            }
+            acc = v[0].box;
+            for (size_t i = 1; i < n; ++i) {
+                if (i > 1) acc = surrounding_box(acc, v[i - 1].box);
+                const double cost = half_area(acc) * (double)i + right_area[i] * (double)(n - i);
+                if (cost < best) { best = cost; best_i = i; best_order = v; }
+            }
+        }
+        if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), items.begin() + (long)lo);
+        return lo + best_i;
+    }
+    uint32_t emit_sah(std::vector<SahItem>& items, size_t lo, size_t hi, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary,
+                      uint32_t* need) {
+        if (hi - lo == 1) return emit(items[lo].id, parent_scope, scope_depth, in_boundary, need);
+        const size_t mid = sah_split(items, lo, hi);
+        AABB lb = items[lo].box, rb = items[mid].box;
+        for (size_t i = lo + 1; i < mid; ++i) lb = surrounding_box(lb, items[i].box);
+        for (size_t i = mid + 1; i < hi; ++i) rb = surrounding_box(rb, items[i].box);
+        const AABB box = surrounding_box(lb, rb);
+        const uint32_t idx = (uint32_t)out.size();
+        RtNode n = blank(RT_BVH2);
+        n.d[0] = box.minimum.x; n.d[1] = box.minimum.y; n.d[2] = box.minimum.z;
+        n.d[3] = box.maximum.x; n.d[4] = box.maximum.y; n.d[5] = box.maximum.z;
+        out.push_back(n);
+        uint32_t na = 0, nb = 0;
+        const uint32_t a = emit_sah(items, lo, mid, parent_scope, scope_depth, in_boundary, &na);
+        const uint32_t b = emit_sah(items, mid, hi, parent_scope, scope_depth, in_boundary, &nb);
+        out[idx].a = a; out[idx].b = b;
+        *need = std::max(2u, std::max(1u + na, nb));
+        return idx;
+    }
+
     /* returns node index; *need = stack entries in use beyond the popped entry of
      * this node while its subtree is processed */
     uint32_t emit(int id, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary, uint32_t* need) {
@@ -161,6 +229,12 @@ struct Flattener {
             case H_AABOX: /* AABox::hit delegates to the side BVH, aabox.rs:88-96 */
                 return emit(h.child, parent_scope, scope_depth, in_boundary, need);
             case H_BVH: {
+                if (s.bvh_build == RT1W_BVH_SAH) {
+                    /* opt-in: the tree over this BVH's leaf set is rebuilt by surface-area heuristic (see emit_sah) */
+                    std::vector<SahItem> items;
+                    if (collect_leaves(id, h.d[0], h.d[1], items) && items.size() >= 2)
+                        return emit_sah(items, 0, items.size(), parent_scope, scope_depth, in_boundary, need);
+                }
                 uint32_t idx = (uint32_t)out.size();
                 RtNode n = blank(h.right >= 0 ? RT_BVH2 : RT_BVH1);
                 n.d[0] = h.box.minimum.x; n.d[1] = h.box.minimum.y; n.d[2] = h.box.minimum.z;
@@ -559,6 +633,7 @@ int rt1w_scene_set_camera(rt1w_scene* s, const double look_from[3], const double
     return RT1W_OK;
 }
 
+static int flatten_scene(rt1w_scene* s);
 int rt1w_scene_commit(rt1w_scene* s) {
     CHECK_SCENE(s);
     if (s->world < 0) { set_error("world not set"); return RT1W_ERR_STATE; }
@@ -575,6 +650,14 @@ int rt1w_scene_commit(rt1w_scene* s) {
         }
     }
     if (s->materials.size() > 0xFFFFu) { set_error("more than 65535 materials"); return RT1W_ERR_UNSUPPORTED; }
+    int rc = flatten_scene(s);
+    if (rc < 0) return rc;
+    s->committed = true;
+    return RT1W_OK;
+}
+
+/* scene graph -> pre-order node records (and the light list); run by commit and again by rt1w_scene_set_bvh_build */
+static int flatten_scene(rt1w_scene* s) {
     s->flat_nodes.clear();
     Flattener f{*s, s->flat_nodes};
     uint32_t need = 0;
@@ -628,7 +711,6 @@ int rt1w_scene_commit(rt1w_scene* s) {
         }
         s->flat_lights.push_back(n);
     }
-    s->committed = true;
     return RT1W_OK;
 }
 
@@ -660,6 +742,7 @@ int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode) {
     if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
     if (mode > RT1W_WALK_NEAR_FAR_ALL) { set_error("unknown walk order"); return RT1W_ERR_INVALID; }
     std::vector<RtNode>& N = s->flat_nodes;
+    uint32_t annotated = 0;
     const uint32_t clear = ~((uint32_t)(RT_BVH_ORDER_MASK << RT_BVH_ORDER_SHIFT) | (uint32_t)RT_BVH_LEFT_LOWER);
     for (uint32_t i = 0; i < N.size(); ++i) {
         if ((N[i].kind & RT_KIND_MASK) != RT_BVH2) continue;
@@ -680,9 +763,28 @@ int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode) {
         if (!(la < ra) && !(la > ra)) continue; /* coincident (or NaN): nothing to order by */
         N[i].kind |= (axis + 1u) << RT_BVH_ORDER_SHIFT;
         if (la < ra) N[i].kind |= RT_BVH_LEFT_LOWER;
+        ++annotated;
     }
+    s->walk_annotated = annotated;
     s->walk_order = mode;
     return RT1W_OK;
+}
+
+int rt1w_scene_set_bvh_build(rt1w_scene* s, uint32_t mode) {
+    if (!s) { set_error("null scene"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
+    if (mode > RT1W_BVH_SAH) { set_error("unknown BVH build"); return RT1W_ERR_INVALID; }
+    const uint32_t before = s->bvh_build;
+    s->bvh_build = mode;
+    int rc = flatten_scene(s);
+    if (rc < 0) { /* e.g. a tree deeper than the traversal stack: back to what it was */
+        const std::string why = rt1w_last_error();
+        s->bvh_build = before;
+        if (flatten_scene(s) < 0) return RT1W_ERR_STATE;
+        set_error(why);
+        return rc;
+    }
+    return rt1w_scene_set_walk_order(s, s->walk_order); /* the order annotations live in the node records */
 }
 
 int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
@@ -698,7 +800,7 @@ int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
     out->has_media = s->has_media ? 1u : 0u;
     out->has_textures = s->has_tex ? 1u : 0u;
     out->has_moving = s->has_msphere ? 1u : 0u;
-    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere, s->scope_depth, s->walk_order != 0u);
+    out->variant = (uint32_t)rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere, s->scope_depth, s->walk_annotated != 0u);
     out->bytes = s->flat_nodes.size() * sizeof(RtNode) + s->flat_lights.size() * sizeof(RtNode) +
                  s->materials.size() * sizeof(RtMaterial) + s->textures.size() * sizeof(RtTexture) +
                  s->perlin.size() * sizeof(RtPerlin) + s->images.size();

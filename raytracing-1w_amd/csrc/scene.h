@@ -56,6 +56,8 @@ struct rt1w_scene {
     uint32_t stack_need = 0, scope_depth = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t walk_order = 0; /* RT1W_WALK_* */
+    uint32_t walk_annotated = 0; /* BVH nodes that carry an order annotation (0: the plain kernels serve) */
+    uint32_t bvh_build = 0;  /* RT1W_BVH_* */
 };
 
 #endif

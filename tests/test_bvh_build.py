@@ -1,0 +1,131 @@
+"""Opt-in BVH build by surface-area heuristic (rt1w_scene_set_bvh_build).
+
+Default = `BVHNode::new` as written: random axis, sort by box minimum, median split (bvh.rs:84-100).  RT1W_BVH_SAH rebuilds the
+tree over every BVH's leaf set.  What must hold: the same leaves (every primitive / wrapper / medium exactly once), boxes that
+are the `surrounding_box` of their children (aabb.rs:42-55), frames BIT-IDENTICAL to the reference build wherever the walk
+order cannot matter (static, media-free arms at test size) and statistically equal where it can (moving spheres -- quirk Q1,
+main.rs:86,145 -- and media, constant_medium.rs:85); switching back restores the reference build byte for byte.  The kernels
+are the same kernels: the GPU frame of a rebuilt scene equals the CPU build of the core on it, bit for bit."""
+import numpy as np
+import pytest
+
+import orc
+from dual import random_scene_pair
+
+ARMS = {0: (96, 64, 8), 1: (48, 28, 4), 2: (48, 28, 4), 3: (48, 28, 4), 4: (48, 28, 8), 5: (48, 48, 8), 6: (48, 48, 8), 7: (56, 56, 6)}
+KIND_BVH2, KIND_BVH1 = 0, 1
+
+
+def _nodes(scene):
+    raw = scene.flat(0)
+    return raw.view(np.uint32).reshape(-1, 24), raw.view(np.float64).reshape(-1, 12)
+
+
+def _leaf_multiset(scene):
+    """(kind, d[0..5], e[0..2], mat) of every non-BVH record, sorted: what the tree is built OVER."""
+    u, f = _nodes(scene)
+    kinds = u[:, 0] & 0xFF
+    rows = [bytes(u[i, 0:1] & 0x1FF) + bytes(f[i, 1:7]) + bytes(f[i, 8:11]) + bytes(u[i, 15:16]) for i in range(len(u)) if kinds[i] > KIND_BVH1]
+    return sorted(rows)
+
+
+@pytest.mark.parametrize("arm", sorted(ARMS))
+def test_sah_build_keeps_the_leaves_and_nests_the_boxes(rt, arm):
+    aspect = 1.5 if arm == 0 else None
+    ref = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
+    sah = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build(True)
+    assert _leaf_multiset(ref) == _leaf_multiset(sah)
+    u, f = _nodes(sah)
+    kinds = u[:, 0] & 0xFF
+    assert sah.info()["n_nodes"] <= ref.info()["n_nodes"]          # no single-child nodes below a root (bvh.rs:63-70 makes them)
+    for i in np.nonzero(kinds == KIND_BVH2)[0]:
+        a, b = int(u[i, 22]), int(u[i, 14])                          # children (RtNode.a, .b), pre-order: a = i + 1
+        assert a == i + 1 and b == int(u[a, 1])                      # .skip of the left child
+        for c in (a, b):
+            if kinds[c] <= KIND_BVH1:                                # a child box lies inside its parent's (an AABox's side BVH: up to the
+                #                                                      rects' 0.0001 pad, aabox.rs:98-103 against aarect.rs:74-79)
+                assert (f[c, 1:4] >= f[i, 1:4] - 2e-4).all() and (f[c, 4:7] <= f[i, 4:7] + 2e-4).all()
+    # back to the reference build: the very same bytes
+    raw_ref = ref.flat(0).tobytes()
+    assert sah.set_bvh_build(False).flat(0).tobytes() == raw_ref
+
+
+@pytest.mark.parametrize("arm", sorted(ARMS))
+def test_sah_build_frames(rt, arm):
+    W, H, spp = ARMS[arm]
+    aspect = 1.5 if arm == 0 else None
+    ref = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
+    sah = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build(True)
+    a, sa = orc.flat_render(ref, W, H, spp)
+    b, sb = orc.flat_render(sah, W, H, spp)
+    differing = int((a != b).any(axis=2).sum())
+    if arm in (1, 2, 3, 4, 5, 6):
+        # static scenes: the closest hit does not depend on the tree (cornel_smoke's two media are reached in the same order)
+        assert differing == 0 and sa["segments"] == sb["segments"], (differing, sa["segments"], sb["segments"])
+    else:
+        # moving spheres (Q1) / media in a big BVH: other paths for a few rays, the same picture
+        assert differing < 0.05 * W * H, differing
+        assert abs(np.nanmean(a) - np.nanmean(b)) < 0.01 * np.nanmean(a)
+        assert abs(sa["segments"] - sb["segments"]) < 0.01 * sa["segments"]
+
+
+def test_sah_build_on_random_graphs(rt):
+    """24 random graphs (mirror boxes, nested wrappers, media, every primitive)."""
+    identical, worst = 0, 0.0
+    for seed in range(24):
+        prod, _ = random_scene_pair(3000 + seed)
+        W, H, spp = 28, 20, 4
+        a, sa = orc.flat_render(prod, W, H, spp, variant=3)
+        leaves = _leaf_multiset(prod)
+        prod.set_bvh_build(True)
+        assert _leaf_multiset(prod) == leaves, seed
+        b, sb = orc.flat_render(prod, W, H, spp, variant=3)
+        same = np.array_equal(a, b, equal_nan=True)
+        identical += same
+        if not same:
+            worst = max(worst, int((a != b).any(axis=2).sum()) / (W * H))
+            assert abs(np.nanmean(a) - np.nanmean(b)) < 0.05 * max(np.nanmean(a), 1e-3), seed
+    print("identical", identical, "of 24; worst differing fraction", worst)
+    assert identical >= 18 and worst < 0.25, (identical, worst)
+
+
+def test_sah_build_with_near_far_order(rt):
+    """The order annotations are recomputed on the rebuilt tree (they live in the node records)."""
+    W, H, spp = ARMS[7]
+    sah = rt.Scene.reference(7, build_seed=1).set_bvh_build(True)
+    a, sa = orc.flat_render(sah, W, H, spp, variant=3)
+    sah.set_walk_order(1)
+    kinds = _nodes(sah)[0][:, 0]
+    assert int((((kinds >> 9) & 3) != 0).sum()) > 0
+    b, sb = orc.flat_render(sah, W, H, spp, variant=4)
+    assert np.array_equal(a, b, equal_nan=True) and sa["segments"] == sb["segments"]
+    nf_first = rt.Scene.reference(7, build_seed=1).set_walk_order(1).set_bvh_build(True)      # the other call order
+    assert nf_first.flat(0).tobytes() == sah.flat(0).tobytes()
+
+
+def test_sah_build_errors(rt):
+    lib = rt._lib
+    sc = rt.Scene.reference(5, build_seed=1)
+    assert lib.rt1w_scene_set_bvh_build(sc._h, 2) < 0 and b"unknown" in lib.rt1w_last_error()
+    assert lib.rt1w_scene_set_bvh_build(None, 1) < 0
+
+
+@pytest.mark.gpu
+def test_sah_build_on_the_gpu(rt, gpu_ctx_factory):
+    """The HIP kernels on rebuilt scenes: stack walk (random_scene, final_scene; also near-far on top and the wavefront form) and
+    the scene-specialised sweep (Cornell: another topology, another generated kernel) -- bit-identical to the CPU build of the core."""
+    for arm, W, H, spp, aspect in ((0, 96, 64, 8, 1.5), (7, 64, 64, 8, None), (5, 64, 64, 16, None)):
+        sc = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build(True)
+        if arm == 7:
+            sc.set_walk_order(1)
+        want, sw = orc.flat_render(sc, W, H, spp)
+        ctx = gpu_ctx_factory(sc)
+        if arm == 5:
+            assert ctx.specialise()["active"]
+        got, sg = ctx.render(W, H, spp)
+        assert np.array_equal(got, want, equal_nan=True) and sg["segments"] == sw["segments"], arm
+        if arm != 5:
+            wf, swf = ctx.render(W, H, spp, wavefront=True)
+            assert np.array_equal(wf, want, equal_nan=True) and swf["segments"] == sw["segments"], arm
+            f32, s32 = ctx.render(W, H, spp, f32=True)
+            assert abs(np.nanmean(f32) - np.nanmean(want)) < 0.02 * np.nanmean(want)
