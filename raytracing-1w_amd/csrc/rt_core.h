@@ -498,6 +498,10 @@ RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_
     }
 }
 
+#ifndef RT_MEDIUM_DEFER
+#define RT_MEDIUM_DEFER 0 /* 0: media run where they are met; 1, 2: parked and run wave-wide (rt_traverse_stack): MEASURED slower,
+                            final_scene 118 -> 106 / 114 Mpaths/s at 16 spp, bit-identical (profiles/r02_medium_defer.txt) */
+#endif
 /* one stack entry */
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
@@ -518,7 +522,47 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root,
                              uint32_t& out_scope) {
     RtWalk k;
     rt_walk_begin(k, root, world, t_min, t_max, stk);
-    while (!rt_walk_done(k, stk)) rt_walk_step<Cfg, MEDIA>(sc, ns, k, rng, stk);
+    if constexpr (MEDIA && Cfg::media && RT_MEDIUM_DEFER != 0) {
+        /* A ConstantMedium costs two complete boundary walks, a logarithm and a draw (rt_walk_other), and the lanes of a wave
+         * reach their media at different steps: run in place, that code executes once per lane with the other 63 waiting
+         * (final_scene: every ray crosses the global fog, constant_medium.rs:58-113 -- 8.7 % of the lanes active, PMC).  So a
+         * lane that pops a medium PARKS on it (it simply does not pop again) while the others walk on, and the wave runs the
+         * medium code for all parked lanes together once no lane can step (RT_MEDIUM_DEFER 1) or once at least as many lanes
+         * are parked as still walk (2).  A lane's own sequence of operations is untouched -- it only waits -- so every bit
+         * of its result is; on the CPU build (one lane) "no lane can step" is true at once and this is the plain loop. */
+        uint32_t parked = RT_NONE;
+        for (;;) {
+            const bool can_step = parked == RT_NONE && !rt_walk_done(k, stk);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const unsigned long long stepping = __ballot(can_step), waiting = __ballot(parked != RT_NONE);
+            if (stepping == 0ull && waiting == 0ull) break;
+            const bool round = stepping == 0ull || (RT_MEDIUM_DEFER == 2 && __popcll(waiting) >= __popcll(stepping));
+#else
+            if (!can_step && parked == RT_NONE) break;
+            const bool round = !can_step;
+#endif
+            if (round) {
+                if (parked != RT_NONE) {
+                    rt_walk_other<Cfg, MEDIA>(sc, ns, k, parked, ns.hot(parked), rng, stk);
+                    parked = RT_NONE;
+                }
+                continue;
+            }
+            if (can_step) {
+                const uint32_t e = stk.pop();
+                if (e & RT_POP_FLAG) { rt_walk_exit(sc, k, e); continue; }
+                const RtNodeHot nd = ns.hot(e);
+                const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
+                RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
+                if (cls == RT_WK_BOX) rt_walk_box<Cfg, Cfg::media>(k, e, nd, stk);
+                else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg>(sc, k, e, nd);
+                else if (cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk);
+                else parked = e;
+            }
+        }
+    } else {
+        while (!rt_walk_done(k, stk)) rt_walk_step<Cfg, MEDIA>(sc, ns, k, rng, stk);
+    }
     out_t = k.best_t; out_prim = k.best_prim; out_scope = k.best_scope;
     return k.best_prim != RT_NONE;
 }

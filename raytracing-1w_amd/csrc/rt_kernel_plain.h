@@ -21,6 +21,9 @@ struct LdsNodes {
     __device__ __forceinline__ RtNodeHot hot(uint32_t n) const { return base[n]; }
 };
 
+#ifndef RT_SLICE_IDLE
+#define RT_SLICE_IDLE 48 /* stack walk: finished lanes of a wave that end a slice of the walk (0: every walk runs to its end) */
+#endif
 /* counters[0] = next work item, counters[1] = traced segments */
 #ifndef RT_SWEEP_WAVES
 #define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
@@ -65,6 +68,9 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
     path.alive = false;
     unsigned long long segs = 0;
 
+    bool walking = false; /* a suspended walk (sliced stack walk below): its closest hit so far and innermost wrapper */
+    double w_best_t = RT_INF;
+    uint32_t w_best_prim = RT_NONE, w_best_scope = RT_NONE, w_scope = RT_NONE;
     for (;;) {
         RT_STAMP(0);
         if (!path.alive) {
@@ -100,11 +106,63 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
             rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
             RT_STAMP(1);
         }
-        segs += path.depth_left != 0u ? 1ull : 0ull;
-        rt_path_step<Cfg>(sc, ns, path, stk);
-        if (!path.alive) {
-            sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
-            ++s;
+        if constexpr (!Cfg::sweep && RT_SLICE_IDLE > 0 && RT_WALK_MODE == 0) {
+            /* ---- stack walk in slices ------------------------------------------------------------------------------
+             * Walk lengths within a wave differ wildly (final_scene: 40 node visits per segment on average, several hundred
+             * through the 1000-sphere cluster), and a wave that runs every walk to its end takes as long as its longest
+             * lane: 122 wave-steps per segment against 40 (tools/walk_sim.cpp).  So the walk is suspended once RT_SLICE_IDLE (48; measured: 16 -13 %, 32 +3 %, 48 +7 %, 56 +6 %, 60 +4 % on random_scene / final_scene)
+             * lanes have finished theirs: those lanes shade, start their next segment (or sample, or work item) and come
+             * back with a fresh walk while the long walkers resume -- their stack is in LDS already, and the walk's rays are
+             * rebuilt from the path's ray and the innermost wrapper by the operations that produced them (what leaving a
+             * wrapper does anyway, rt_walk_exit).  A lane's own operations and their order do not change: same bits. */
+            if (!walking) {
+                segs += path.depth_left != 0u ? 1ull : 0ull;
+                w_best_t = RT_INF; w_best_prim = RT_NONE; w_best_scope = RT_NONE; w_scope = RT_NONE;
+                if (path.depth_left != 0u) { stk.push(sc.root); walking = true; }
+            }
+            RtTrace tr;
+            tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
+            if (walking) {
+                RtWalk k;
+                k.w.o = path.ray.o; k.w.d = path.ray.d;
+                k.inv_w = rt_inv3(k.w.d);
+                k.time = path.ray.time; k.t_min = 0.001; k.tmin_nan = false; k.base = 0;
+                k.best_t = w_best_t; k.best_prim = w_best_prim; k.best_scope = w_best_scope; k.scope = w_scope;
+                if (w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
+                else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }
+                const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
+                const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE ? lanes_here - (uint32_t)RT_SLICE_IDLE : 0u;
+                for (;;) {
+                    const bool more = !rt_walk_done(k, stk);
+                    if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
+                    if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
+                }
+                if (rt_walk_done(k, stk)) {
+                    walking = false;
+                    tr.t = k.best_t; tr.prim = k.best_prim; tr.scope = k.best_scope;
+                    if (tr.prim != RT_NONE) {
+                        const uint32_t mk = RT_MAT_KINDF(ns.hot(tr.prim).mat) & 0xFFu;
+                        tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
+                               : mk == RT_MAT_METAL ? RT_CLS_METAL : mk == RT_MAT_ISOTROPIC ? RT_CLS_OTHER : RT_CLS_TERMINAL;
+                    }
+                } else {
+                    w_best_t = k.best_t; w_best_prim = k.best_prim; w_best_scope = k.best_scope; w_scope = k.scope;
+                }
+            }
+            if (!walking) {
+                rt_path_shade<Cfg>(sc, path, tr);
+                if (!path.alive) {
+                    sum = rt_v3d_add(sum, path.radiance);
+                    ++s;
+                }
+            }
+        } else {
+            segs += path.depth_left != 0u ? 1ull : 0ull;
+            rt_path_step<Cfg>(sc, ns, path, stk);
+            if (!path.alive) {
+                sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
+                ++s;
+            }
         }
         RT_STAMP(6);
     }

@@ -1,0 +1,50 @@
+// tools/visit_hist.cpp -- node visits per segment by node kind, reference build against the opt-in SAH rebuild (and near-far order), from the
+// CPU build of the core (measurement tool, not product).  Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Iraytracing-1w_amd/csrc
+// tools/visit_hist.cpp -o /tmp/visit_hist -Lraytracing-1w_amd -lrt1w -Wl,-rpath,$PWD/raytracing-1w_amd ; /tmp/visit_hist <arm> <W> <H> <spp>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <vector>
+static thread_local unsigned long long g_hist[16];
+#define RT_STAT_VISIT(kind) do { ++g_hist[(kind) & 15]; } while (0)
+#include "rt_core.h"
+#include "rt1w.h"
+struct HostStack { uint32_t e[64]; int sp = 0; void push(uint32_t v) { e[sp++] = v; } uint32_t pop() { return e[--sp]; } };
+struct cam_bg { RtCamera cam; RtV3 bg; uint32_t root, pad; };
+int main(int argc, char** argv) {
+    int arm = atoi(argv[1]), W = atoi(argv[2]), H = atoi(argv[3]), spp = atoi(argv[4]);
+    static const char* names[16] = {"bvh2", "bvh1", "sphere", "msphere", "xy", "xz", "yz", "translate", "rotate_y", "flip", "medium", "?", "?", "?", "?", "?"};
+    for (int mode = 0; mode < 4; ++mode) {
+        std::vector<uint8_t> earth(1024 * 512 * 3, 128);
+        rt1w_scene* s = nullptr; uint32_t def[3];
+        if (rt1w_scene_build_reference(arm, 1, (double)W / H, earth.data(), 1024, 512, &s, def)) { printf("fail\n"); return 1; }
+        if (mode & 1) rt1w_scene_set_bvh_build(s, RT1W_BVH_SAH);
+        if (mode & 2) rt1w_scene_set_walk_order(s, RT1W_WALK_NEAR_FAR);
+        std::vector<std::vector<uint8_t>> a(7);
+        for (int i = 0; i < 7; i++) { int64_t n = rt1w_scene_copy_flat(s, i, nullptr, 0); a[i].resize(n > 0 ? n + 96 : 16); rt1w_scene_copy_flat(s, i, a[i].data(), a[i].size()); }
+        rt1w_scene_info inf; rt1w_scene_get_info(s, &inf);
+        RtSceneView sc; memset(&sc, 0, sizeof sc);
+        const cam_bg* cb = (const cam_bg*)a[6].data();
+        sc.nodes = (const RtNode*)a[0].data(); sc.lights = (const RtNode*)a[1].data(); sc.materials = (const RtMaterial*)a[2].data(); sc.textures = (const RtTexture*)a[3].data();
+        sc.perlin = (const RtPerlin*)a[4].data(); sc.images = a[5].data(); sc.root = cb->root; sc.n_nodes = inf.n_nodes; sc.n_lights = inf.n_lights; sc.n_materials = inf.n_materials; sc.n_textures = inf.n_textures;
+        sc.camera = cb->cam; sc.background = cb->bg;
+        RtFrame f; memset(&f, 0, sizeof f); f.width = W; f.height = H; f.tile_w = W; f.tile_h = H; f.spp = spp; f.max_depth = 50; f.chunk = spp; f.n_chunks = 1;
+        HostStack stk; RtGlobalNodes ns{sc.nodes};
+        memset(g_hist, 0, sizeof g_hist);
+        unsigned long long segs = 0;
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) for (int k = 0; k < spp; k++) {
+            RtPath p; rt_path_begin(sc, f, x, y, k, p);
+            while (p.alive) {
+                segs += p.depth_left != 0u;
+                RtTrace tr = (mode & 2) ? rt_path_trace<RtCfgV4>(sc, ns, p, stk) : rt_path_trace<RtCfgV3>(sc, ns, p, stk);
+                rt_path_shade<RtCfgV3>(sc, p, tr);
+            }
+        }
+        unsigned long long tot = 0; for (int i = 0; i < 16; i++) tot += g_hist[i];
+        printf("arm %d %-9s%-9s nodes %5u: %.2f visits/segment:", arm, (mode & 1) ? "SAH" : "reference", (mode & 2) ? "+near-far" : "", inf.n_nodes, (double)tot / segs);
+        for (int i = 0; i < 11; i++) if (g_hist[i]) printf(" %s %.2f", names[i], (double)g_hist[i] / segs);
+        printf("\n");
+        rt1w_scene_destroy(s);
+    }
+}
