@@ -130,6 +130,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 k.best_t = w_best_t; k.best_prim = w_best_prim; k.best_scope = w_best_scope; k.scope = w_scope;
                 if (w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
                 else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }
+                RT_STAMP(7); /* bucket 7 here: rebuilding the walk's rays */
                 const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
                 const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE ? lanes_here - (uint32_t)RT_SLICE_IDLE : 0u;
                 for (;;) {
@@ -137,6 +138,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                     if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
                     if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
                 }
+                RT_STAMP(2);
                 if (rt_walk_done(k, stk)) {
                     walking = false;
                     tr.t = k.best_t; tr.prim = k.best_prim; tr.scope = k.best_scope;

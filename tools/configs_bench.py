@@ -1,6 +1,6 @@
 """Kernel-time throughput of the BASELINE configurations' geometry at reduced spp (Mpaths/s does not depend on spp):
 C2 random_scene 1200x800, C3 Cornell 600x600, C4 final_scene 800x800, C5 Cornell 3840x2160, plus cornel_smoke 600x600 --
-the default (exact f64) kernels, then the opt-in forms: wavefront, near-far walk order, f32, the reference's own stream."""
+the default (exact f64) kernels, then the opt-in forms: wavefront, near-far walk order, SAH rebuild, f32, the reference's own stream."""
 import importlib
 import os
 import sys
@@ -43,6 +43,13 @@ for name, arm, aspect, W, H, spp in (("C2 random_scene", 0, 1.5, 1200, 800, 100)
         o32, _ = best_of(nf, W, H, spp, f32=True)
         line += f" | near-far+f32 {o32:7.1f}"
         nf.close()
+        sah = rt.Context(rt.Scene.reference(arm, aspect_ratio=aspect).set_bvh_build(True).set_walk_order(1), 0)
+        sah.render(W, H, 2)
+        o, _ = best_of(sah, W, H, spp)
+        line += f" | SAH+near-far {o:7.1f}"
+        o32, _ = best_of(sah, W, H, spp, f32=True)
+        line += f" | SAH+near-far+f32 {o32:7.1f}"
+        sah.close()
     f32, s32 = best_of(ctx, W, H, spp, f32=True)
     line += f" | f32 {f32:7.1f}"
     ref, _ = best_of(ctx, W, H, min(spp, 100), reference_stream=True)
