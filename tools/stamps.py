@@ -1,11 +1,13 @@
 """Per-phase cycle shares of the reordering render kernel.
   python tools/stamps.py [arms...]        generic kernels of the diagnostic build librt1w_stamps.so (make -C raytracing-1w_amd/csrc stamps)
-  python tools/stamps.py --jit [arms...]  the scene-specialised kernel, compiled here with the counters in (RT1W_JIT_STAMPS=1)"""
+  python tools/stamps.py --jit [arms...]  the scene-specialised kernel, compiled here with the counters in (RT1W_JIT_STAMPS=1)
+  python tools/stamps.py --walk [arms...] stamps library built with -DRT_STAMPS_WALK as well: the stack walk's time by node kind"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
 jit = "--jit" in args
-args = [a for a in args if a != "--jit"]
+walk = "--walk" in args   # library built with tools/experiments/walk_stamps.patch applied and -DRT_STAMPS -DRT_STAMPS_WALK: buckets 8-13 are the stack walk's kinds
+args = [a for a in args if a not in ("--jit", "--walk")]
 if jit:
     os.environ["RT1W_JIT_STAMPS"] = "1"
     os.environ.setdefault("RT1W_KERNEL_CACHE", "/tmp/rt1w_stamps_cache")
@@ -15,6 +17,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc
 rt = orc.rt()
 names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+tail", "loop top", "exchange: read", "sort: ballots+counts", "sort: barrier 1 wait", "exchange: rank+write", "exchange: barrier 2 wait", "-", "-", "-", "-"]
+if walk:
+    names[8:14] = ["walk: pop + fetch + class", "walk: box", "walk: leaf", "walk: wrapper entry", "walk: wrapper exit", "walk: medium (outside its boundary walks)"]
+    names[2] = "walk: loop control, slice votes"
 for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), (400, 400, 32)) for a in args):
     sc = rt.Scene.reference(arm)
     ctx = rt.Context(sc, 0)
