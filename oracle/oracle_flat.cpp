@@ -96,6 +96,7 @@ int orcflat_render(const void* nodes, uint32_t n_nodes, const void* lights, uint
                         case 1: run_path<RtCfgV1>(sc, f, px, py, s, stk, sum, segs, path); break;
                         case 2: run_path<RtCfgV2>(sc, f, px, py, s, stk, sum, segs, path); break;
                         case 4: run_path<RtCfgV4>(sc, f, px, py, s, stk, sum, segs, path); break;
+                        case 5: run_path<RtCfgV5>(sc, f, px, py, s, stk, sum, segs, path); break;
 #ifdef ORC_STATIC_CASES
                         ORC_STATIC_CASES
 #endif

@@ -150,9 +150,9 @@ struct rt1w_context {
     void* d_textures = nullptr; void* d_perlin = nullptr; void* d_images = nullptr;
     RtSceneView view{};
     double* d_out = nullptr; size_t out_bytes = 0;
-    int grid[RT_N_VARIANTS] = {0, 0, 0, 0, 0};
-    int grid_sorted[RT_N_VARIANTS] = {0, 0, 0, 0, 0};
-    int grid_cached[RT_N_VARIANTS] = {0, 0, 0, 0, 0};
+    int grid[RT_N_VARIANTS] = {};
+    int grid_sorted[RT_N_VARIANTS] = {};
+    int grid_cached[RT_N_VARIANTS] = {};
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
@@ -166,7 +166,7 @@ struct rt1w_context {
     uint32_t stack_need = 0;
     int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
     void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays */
-    int f32_grid[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int f32_grid[RT_N_VARIANTS][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
     hipModule_t jit_mod = nullptr;
@@ -184,13 +184,14 @@ struct rt1w_context {
 
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
 static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV0>, rt_render_kernel<RtCfgV1>,
-                                                         rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>, rt_render_kernel<RtCfgV4>};
+                                                         rt_render_kernel<RtCfgV2>, rt_render_kernel<RtCfgV3>, rt_render_kernel<RtCfgV4>,
+                                                         rt_render_kernel<RtCfgV5>};
 /* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
  * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
-static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr};
+static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr, rt_render_kernel<RtCfgV5, true>};
 /* the reordering kernel exists for the variants where it pays (measured): the sweep variants */
 static render_kernel_t const g_kernels_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted<RtCfgV0>, rt_render_kernel_sorted<RtCfgV1>,
-                                                                nullptr, nullptr, nullptr}; /* stack variants: measured 0.55x (LDS for stack + exchange halves occupancy) */
+                                                                nullptr, nullptr, nullptr, nullptr}; /* stack variants: measured 0.55x (LDS for stack + exchange halves occupancy) */
 
 namespace {
 
@@ -272,10 +273,10 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     L.ref = false; L.f32 = false;
     if (p->precision == RT1W_PRECISION_F32) {
         if (p->flags & (RT1W_RNG_REFERENCE | RT1W_WAVEFRONT | RT1W_LDS_NODES)) { rt1w::set_error("RT1W_PRECISION_F32 has the default kernels only"); return RT1W_ERR_INVALID; }
-        int v = c->variant > 3 ? 3 : c->variant;
+        int v = c->variant == 4 ? 3 : c->variant; /* the order-aware variant exists in f64 only */
         if (p->flags >> 8) {
             v = (int)((p->flags >> 8) & 0xFFu) - 1;
-            if (v > 3 || !rt_variant_valid(v, c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth)) {
+            if (v == 4 || !rt_variant_valid(v, c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth)) {
                 rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
             }
         }
@@ -468,7 +469,7 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
     RtLane& l = c->lane[0];
     const RtFrame& f = L.f;
     const unsigned long long npix = L.npix;
-    const int v = L.variant;
+    const int v = L.variant == 5 ? 2 : L.variant; /* no kernels of its own for the wrapper-free variant: V2's cover it */
     if (v < 2) { rt1w::set_error("the wavefront form exists for the stack-walk variants only"); return RT1W_ERR_INVALID; }
     if (npix > RT_WF_PASS_PATHS) { rt1w::set_error("wavefront form: tile larger than one pass (render it in strips)"); return RT1W_ERR_UNSUPPORTED; }
     if (f.max_depth > WF_MAX_BOUNCES) { rt1w::set_error("wavefront form: max_depth above WF_MAX_BOUNCES"); return RT1W_ERR_UNSUPPORTED; }

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, 4) void rt_render_kernel_sorted_f32(
     rt_render_sorted_body<Cfg>(sc, f, partial, counters);
 }
 typedef void (*kernel_t)(RtSceneView, RtFrame, rt_f64*, unsigned long long*);
-static kernel_t const g_plain[4] = {rt_render_kernel_f32<RtCfgV0>, rt_render_kernel_f32<RtCfgV1>, rt_render_kernel_f32<RtCfgV2>, rt_render_kernel_f32<RtCfgV3>};
-static kernel_t const g_sorted[4] = {rt_render_kernel_sorted_f32<RtCfgV0>, rt_render_kernel_sorted_f32<RtCfgV1>, nullptr, nullptr};
+static kernel_t const g_plain[RT_N_VARIANTS] = {rt_render_kernel_f32<RtCfgV0>, rt_render_kernel_f32<RtCfgV1>, rt_render_kernel_f32<RtCfgV2>, rt_render_kernel_f32<RtCfgV3>,
+                                                nullptr, rt_render_kernel_f32<RtCfgV5>};
+static kernel_t const g_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted_f32<RtCfgV0>, rt_render_kernel_sorted_f32<RtCfgV1>, nullptr, nullptr, nullptr, nullptr};
 } // namespace rtf32
 
 #undef double
@@ -161,6 +162,7 @@ extern "C" unsigned rt1w_internal_f32_view(void* h, void* out, unsigned cap) {
 
 extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted) {
     int per_cu = 0;
+    if (variant < 0 || variant >= RT_N_VARIANTS) return 0;
     rtf32::kernel_t k = sorted ? rtf32::g_sorted[variant] : rtf32::g_plain[variant];
     if (!k) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, sorted ? RT_SORT_BLOCK : RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -171,6 +173,7 @@ extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted) {
 extern "C" int rt1w_internal_f32_launch(void* h, int variant, int sorted, const void* frame, double* partial, unsigned long long* counters, int grid,
                                         hipStream_t stream) {
     F32Scene* s = static_cast<F32Scene*>(h);
+    if (variant < 0 || variant >= RT_N_VARIANTS) return -1;
     rtf32::kernel_t k = sorted ? rtf32::g_sorted[variant] : rtf32::g_plain[variant];
     if (!s || !k) return -1;
     rtf32::RtFrame f;

@@ -304,7 +304,7 @@ RT_HD void rt_finish_hit(const RtSceneView& sc, const RtRay& world, uint32_t pri
     const RtNode& nd = nodes[prim];
     bool want_uv = Cfg::tex && (RT_MAT_KINDF(nd.mat) & RT_MAT_NEEDS_UV) != 0u;
     RtRayOD r0; r0.o = world.o; r0.d = world.d;
-    if (scope == RT_NONE) {
+    if (Cfg::scope_depth == 0 || scope == RT_NONE) {
         rt_leaf_record<Cfg>(nd, r0, world.time, t, want_uv, h);
         return;
     }
@@ -506,14 +506,14 @@ RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
     uint32_t e = stk.pop();
-    if (e & RT_POP_FLAG) { rt_walk_exit(sc, k, e); return; }
+    if (Cfg::scope_depth > 0 && (e & RT_POP_FLAG)) { rt_walk_exit(sc, k, e); return; }
     const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
     const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
     RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
     if (cls == RT_WK_BOX) rt_walk_box<Cfg, Cfg::media>(k, e, nd, stk); /* media scenes: boundary walks run with few lanes */
     else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg>(sc, k, e, nd);
-    else if (cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk);
-    else rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
+    else if (Cfg::scope_depth > 0 && cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk); /* scope_depth 0: the scene has no wrapper node */
+    else if (Cfg::media) rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
 }
 
 template <class Cfg, bool MEDIA, class Stack, class NS>

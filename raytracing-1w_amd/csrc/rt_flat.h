@@ -166,7 +166,8 @@ template <bool MEDIA_, bool TEX_, bool MSPHERE_, bool SWEEP_, int SCOPE_DEPTH_ =
 struct RtCfg {
     static constexpr bool ordered = ORDERED_; /* stack walk honours the opt-in near-far bits of BVH2 nodes (rt1w_scene_set_walk_order) */
     typedef Topo_ Topo;
-    static constexpr int scope_depth = SCOPE_DEPTH_; /* deepest wrapper nesting the sweep variant handles */
+    static constexpr int scope_depth = SCOPE_DEPTH_; /* deepest wrapper nesting the variant handles; 0: the scene has no Translate / RotateY / FlipFace
+                                                        node at all, and the walk carries neither a wrapper's ray nor its entry/exit code */
     static constexpr bool media = MEDIA_;     /* scene contains ConstantMedium nodes */
     static constexpr bool tex = TEX_;         /* scene has non-solid textures (checker/noise/image) */
     static constexpr bool msphere = MSPHERE_; /* scene has MovingSphere primitives */
@@ -178,11 +179,13 @@ typedef RtCfg<true, true, true, true> RtCfgV1;    /* small scene, every feature 
 typedef RtCfg<false, true, true, false> RtCfgV2;  /* large scene without media (random_scene) */
 typedef RtCfg<true, true, true, false> RtCfgV3;   /* large scene, every feature (final_scene) */
 typedef RtCfg<true, true, true, false, 3, void, true> RtCfgV4; /* V3 + the opt-in near-far walk order (only scenes that asked for it) */
-#define RT_N_VARIANTS 5
+typedef RtCfg<false, true, true, false, 0> RtCfgV5; /* large scene without media and without wrappers (random_scene): one ray space */
+#define RT_N_VARIANTS 6
 /* cheapest valid variant for a scene; `force` >= 0 overrides when valid */
 inline int rt_pick_variant(uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth, bool ordered = false) {
     if (n_nodes <= RT_SWEEP_MAX_NODES) return (!media && !tex && !msphere && scope_depth <= 2u) ? 0 : 1;
     if (ordered) return 4;
+    if (!media && scope_depth == 0u) return 5;
     return media ? 3 : 2;
 }
 inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool msphere, uint32_t scope_depth) {
@@ -193,6 +196,7 @@ inline bool rt_variant_valid(int v, uint32_t n_nodes, bool media, bool tex, bool
         case 2: return !media;
         case 3: return true;
         case 4: return true; /* reference order unless the scene's nodes carry order bits */
+        case 5: return !media && scope_depth == 0u;
         default: return false;
     }
 }

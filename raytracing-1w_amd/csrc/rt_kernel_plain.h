@@ -128,7 +128,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 k.inv_w = rt_inv3(k.w.d);
                 k.time = path.ray.time; k.t_min = 0.001; k.tmin_nan = false; k.base = 0;
                 k.best_t = w_best_t; k.best_prim = w_best_prim; k.best_scope = w_best_scope; k.scope = w_scope;
-                if (w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
+                if (Cfg::scope_depth == 0 || w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
                 else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }
                 RT_STAMP(7); /* bucket 7 here: rebuilding the walk's rays */
                 const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));

@@ -87,12 +87,12 @@ def test_c1_cornell_200x200x64_against_golden(rt):
     assert np.allclose(bm, gold["c1_cornell_200x200x64__block20"], rtol=1e-11, atol=0)
 
 
-VALID = {0: (1, 2, 3), 1: (1, 3), 2: (1, 3), 3: (1, 3), 4: (1, 3), 5: (0, 1, 2, 3), 6: (1, 3), 7: (1, 3)}
+VALID = {0: (1, 2, 3, 5), 1: (1, 3), 2: (1, 3), 3: (1, 3), 4: (1, 3), 5: (0, 1, 2, 3), 6: (1, 3), 7: (1, 3)}   # V5: no media, no wrapper node
 
 
 @pytest.mark.parametrize("arm", sorted(CASES))
 def test_every_valid_kernel_variant_gives_identical_bits(rt, arm):
-    """V0/V1 = stackless pre-order sweep, V2/V3 = stack walk; feature-pruned or full.  All must visit the
+    """V0/V1 = stackless pre-order sweep, V2/V3/V5 = stack walk; feature-pruned or full.  All must visit the
     same nodes in the same order with the same arithmetic: bit-identical framebuffers, equal segment counts."""
     W, H, spp = CASES[arm]
     sc = rt.Scene.reference(arm, build_seed=1)
@@ -108,7 +108,7 @@ def test_every_valid_kernel_variant_gives_identical_bits(rt, arm):
 def test_variant_selection_rule(rt):
     assert rt.Scene.reference(5).info()["variant"] == 0      # Cornell: 30 nodes, solid colours, no media
     assert rt.Scene.reference(6).info()["variant"] == 1      # cornel_smoke: small, media
-    assert rt.Scene.reference(0).info()["variant"] == 2      # random_scene: ~1000 nodes, checker, moving spheres
+    assert rt.Scene.reference(0).info()["variant"] == 5      # random_scene: ~1000 nodes, checker, moving spheres, no wrapper node (V2 would do too)
     assert rt.Scene.reference(7).info()["variant"] == 3      # final_scene
     i = rt.Scene.reference(0).info()
     assert i["has_textures"] == 1 and i["has_moving"] == 1 and i["has_media"] == 0

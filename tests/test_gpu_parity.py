@@ -102,7 +102,7 @@ def test_gpu_bit_exact_vs_core_and_close_to_literal(rt, gpu_ctx_factory, arm):
 
 def test_gpu_kernel_variants_agree(rt, gpu_ctx_factory):
     """Forced variants on the GPU (sweep vs stack, pruned vs full) == the CPU build, bit for bit."""
-    for arm, variants in ((5, (0, 1, 2, 3)), (6, (1, 3)), (0, (1, 2, 3)), (7, (3,))):
+    for arm, variants in ((5, (0, 1, 2, 3)), (6, (1, 3)), (0, (1, 2, 3, 5)), (7, (3,))):
         W, H, spp = SMALL[arm]
         sc = rt.Scene.reference(arm, build_seed=1)
         ctx = gpu_ctx_factory(sc)

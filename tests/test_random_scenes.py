@@ -21,8 +21,9 @@ def test_random_scene_graph_flat_core_vs_literal_oracle(rt, seed):
     W, H, spp = 28, 20, 4
     a, sa = oracle.render(W, H, spp)
     ref = None
-    for v in range(4):
-        valid = (v in (1, 3)) or (v == 0 and info["variant"] == 0) or (v == 2 and not info["has_media"])
+    for v in (0, 1, 2, 3, 5):
+        valid = (v in (1, 3)) or (v == 0 and info["variant"] == 0) or (v == 2 and not info["has_media"]) or \
+                (v == 5 and not info["has_media"] and info["scope_depth"] == 0)
         if not valid:
             continue
         b, sb = orc.flat_render(prod, W, H, spp, variant=v)

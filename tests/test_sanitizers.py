@@ -19,7 +19,7 @@ SCRIPT = textwrap.dedent("""
     B = orc.B
     B.orcflat_render.restype = ctypes.c_int
     rt = orc.rt()
-    for arm, (W, H, spp), variants in ((5, (24, 24, 4), (0, 1, 3)), (0, (24, 16, 2), (1, 2, 3)), (6, (20, 20, 4), (1, 3)),
+    for arm, (W, H, spp), variants in ((5, (24, 24, 4), (0, 1, 3)), (0, (24, 16, 2), (1, 2, 3, 5)), (6, (20, 20, 4), (1, 3)),
                                        (7, (16, 16, 4), (1, 3)), (3, (16, 9, 2), (1, 3)), (2, (16, 9, 2), (1, 3))):
         sc = rt.Scene.reference(arm, build_seed=1)
         ref = None
