@@ -155,7 +155,7 @@ typedef struct rt1w_scene_info {
     uint32_t has_media;
     uint32_t has_textures; /* any non-solid texture */
     uint32_t has_moving;   /* any MovingSphere */
-    uint32_t variant;      /* kernel variant rt1w_render picks (V0..V3) */
+    uint32_t variant;      /* kernel variant rt1w_render picks (V0..V5) */
     uint64_t bytes;        /* bytes uploaded per context */
 } rt1w_scene_info;
 int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out);
@@ -210,7 +210,7 @@ typedef struct rt1w_stats {
     double total_ms;       /* host wall time of the call incl. device->host copy */
     uint32_t chunk, n_chunks;
     uint32_t grid, block;
-    uint32_t variant;      /* feature variant of the kernel (V0..V4: rt_flat.h).  With bit 2 of `sorted` set the kernel that ran is the
+    uint32_t variant;      /* feature variant of the kernel (V0..V5: rt_flat.h).  With bit 2 of `sorted` set the kernel that ran is the
                               scene-specialised SWEEP kernel whatever walk this number names (scenes of 65-256 nodes report a stack
                               variant here because that is what the generic code would have used) */
     uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: node records in LDS; bit 2: scene-specialised kernel; bit 3:
