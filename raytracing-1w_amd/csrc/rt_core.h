@@ -437,11 +437,25 @@ RT_HD void rt_walk_exit(const RtSceneView& sc, RtWalk& k, uint32_t e) {
     if (k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
     else { k.cur = rt_ray_in_scope(nodes, k.scope, k.w); k.inv = rt_inv3(k.cur.d); }
 }
+#ifndef RT_BRANCHLESS_PUSH
+#define RT_BRANCHLESS_PUSH 1
+#endif
 template <class Cfg, bool EARLY, class Stack>
 RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
     bool hit;
     if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
     else hit = rt_aabb_hit_fast<EARLY>(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
+#if RT_BRANCHLESS_PUSH && defined(__HIP_DEVICE_COMPILE__) /* the CPU build keeps the pushes it can bound-check */
+    if constexpr (!Cfg::ordered) {
+        /* both slots are written whatever the test said and the stack pointer moves by 0, 1 or 2: no nested exec-mask regions
+         * (a miss leaves two dead words above the top; the flattener's stack bound is the bound of the hit case) */
+        const bool two = (nd.kind & RT_KIND_MASK) == RT_BVH2;
+        stk.poke(0, two ? nd.b : e + 1u); /* BVH2: the right child below the left one (bvh.rs:38-47); BVH1: its only child */
+        stk.poke(1, e + 1u);
+        stk.sp += hit ? (two ? 2 : 1) : 0;
+        return;
+    }
+#endif
     if (hit) {
         if ((nd.kind & RT_KIND_MASK) == RT_BVH2) {
             uint32_t first = e + 1u, second = nd.b; /* left child = the next node in pre-order, then the right one: bvh.rs:38-47 */

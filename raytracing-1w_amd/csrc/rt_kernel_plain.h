@@ -11,6 +11,7 @@ struct LdsStack16 {
     uint16_t* base;
     int sp;
     __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); ++sp; }
+    __device__ __forceinline__ void poke(int above, uint32_t v) { base[(sp + above) * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); }
     __device__ __forceinline__ uint32_t pop() { --sp; uint32_t x = base[sp * RT_BLOCK]; return (x & 0x7FFFu) | ((x & 0x8000u) ? RT_POP_FLAG : 0u); }
 };
 /* hot halves of all nodes copied into LDS once per workgroup (scenes of <= RT_LDS_NODE_CAP nodes): the

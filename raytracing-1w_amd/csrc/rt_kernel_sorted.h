@@ -30,6 +30,7 @@ struct LdsStack {
     uint32_t* base; /* this lane's entry 0; entry e at base[e * RT_BLOCK] */
     int sp;
     __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
+    __device__ __forceinline__ void poke(int above, uint32_t v) { base[(sp + above) * RT_BLOCK] = v; } /* write without moving the top */
     __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
 };
 

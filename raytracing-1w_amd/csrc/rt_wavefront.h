@@ -152,6 +152,7 @@ struct WfStack {
     uint32_t* base; /* this lane's entry 0; entry e at base[e * STRIDE] (bank = lane: conflict-free at any depth) */
     int sp;
     __device__ __forceinline__ void push(uint32_t v) { base[sp * STRIDE] = v; ++sp; }
+    __device__ __forceinline__ void poke(int above, uint32_t v) { base[(sp + above) * STRIDE] = v; }
     __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * STRIDE]; }
 };
 #define RT_WF_LDS_BLOCK 1024 /* workgroup of the LDS-resident form: one per CU, 4 waves per SIMD */
