@@ -138,6 +138,9 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                     const bool more = !rt_walk_done(k, stk);
                     if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
                     if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
+                    /* a second step on the same vote where a step is cheap (measured: random_scene +1.8 %; final_scene, whose steps
+                     * can be a whole medium, -4 %) */
+                    if constexpr (!Cfg::media) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
                 }
                 RT_STAMP(2);
                 if (rt_walk_done(k, stk)) {
