@@ -403,11 +403,13 @@ struct RtWalk {
     bool tmin_nan;
 };
 
+/* `inv_known`: 1/direction of `world` if the caller has it already (a ConstantMedium's boundary is walked with the very ray the
+ * outer walk holds, constant_medium.rs:62-69: the same three quotients, not computed again twice per medium) */
 template <class Stack>
-RT_HD void rt_walk_begin(RtWalk& k, uint32_t root, const RtRay& world, double t_min, double t_max, Stack& stk) {
+RT_HD void rt_walk_begin(RtWalk& k, uint32_t root, const RtRay& world, double t_min, double t_max, Stack& stk, const RtV3* inv_known = nullptr) {
     k.w.o = world.o; k.w.d = world.d;
     k.cur = k.w;
-    k.inv_w = rt_inv3(k.w.d);
+    k.inv_w = inv_known ? *inv_known : rt_inv3(k.w.d);
     k.inv = k.inv_w;
     k.time = world.time; k.t_min = t_min; k.best_t = t_max;
     k.scope = RT_NONE; k.best_prim = RT_NONE; k.best_scope = RT_NONE;
@@ -421,7 +423,7 @@ RT_HD bool rt_walk_done(const RtWalk& k, const Stack& stk) { return stk.sp <= k.
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
-                             uint32_t& out_scope);
+                             uint32_t& out_scope, const RtV3* inv_known = nullptr);
 
 /* The walk's work, one piece per kind of stack entry (MEDIA=false is the flavour used for a ConstantMedium's
  * boundary, where only t is consumed, constant_medium.rs:62-69). */
@@ -504,9 +506,18 @@ RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_
         /* ConstantMedium::hit constant_medium.rs:58-113: two complete boundary walks, then the free-flight draw */
         RtRay br; br.o = k.cur.o; br.d = k.cur.d; br.time = k.time;
         double t1, t2, t; uint32_t p_, s_;
-        if (rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_) &&
-            rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_) &&
-            rt_medium_t(sc.nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
+        bool both;
+        const RtNodeHot bn = ns.hot(e + 1u);
+        if ((bn.kind & RT_KIND_MASK) == RT_SPHERE) {
+            /* the boundary is a bare Sphere (every medium of the reference's scenes): its walk is one stack entry, one leaf
+             * test -- run the two tests (sphere.rs:31-48 with (-inf, inf), then (t1 + 0.0001, inf)) without the walk around them */
+            const RtV3 c = rt_v3(bn.d[0], bn.d[1], bn.d[2]);
+            both = rt_sphere_root(c, bn.d[3], br.o, br.d, -RT_INF, RT_INF, t1) && rt_sphere_root(c, bn.d[3], br.o, br.d, t1 + 0.0001, RT_INF, t2);
+        } else {
+            both = rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_, &k.inv) &&
+                   rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_, &k.inv);
+        }
+        if (both && rt_medium_t(sc.nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
             k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
         }
     }
@@ -534,9 +545,9 @@ RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& r
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,
-                             uint32_t& out_scope) {
+                             uint32_t& out_scope, const RtV3* inv_known) {
     RtWalk k;
-    rt_walk_begin(k, root, world, t_min, t_max, stk);
+    rt_walk_begin(k, root, world, t_min, t_max, stk, inv_known);
     if constexpr (MEDIA && Cfg::media && RT_MEDIUM_DEFER != 0) {
         /* A ConstantMedium costs two complete boundary walks, a logarithm and a draw (rt_walk_other), and the lanes of a wave
          * reach their media at different steps: run in place, that code executes once per lane with the other 63 waiting
