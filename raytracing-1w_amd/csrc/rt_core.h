@@ -250,6 +250,17 @@ RT_HD RtRayOD rt_ray_in_scope(const RtNode* nodes, uint32_t scope, RtRayOD world
     if (c.s2 != RT_NONE) r = rt_scope_in(nodes[c.s2], r);
     return r;
 }
+/* the same, also telling whether a RotateY is among the wrappers: if none is, the direction -- and 1/direction -- is the world's */
+RT_HD RtRayOD rt_ray_in_scope_r(const RtNode* nodes, uint32_t scope, RtRayOD world, bool& rotated) {
+    rotated = false;
+    if (scope == RT_NONE) return world;
+    RtChain c = rt_chain(nodes, scope);
+    rotated = (nodes[c.s0].kind & RT_KIND_MASK) == RT_ROTATE_Y;
+    RtRayOD r = rt_scope_in(nodes[c.s0], world);
+    if (c.s1 != RT_NONE) { rotated |= (nodes[c.s1].kind & RT_KIND_MASK) == RT_ROTATE_Y; r = rt_scope_in(nodes[c.s1], r); }
+    if (c.s2 != RT_NONE) { rotated |= (nodes[c.s2].kind & RT_KIND_MASK) == RT_ROTATE_Y; r = rt_scope_in(nodes[c.s2], r); }
+    return r;
+}
 
 /* sphere_uv math.rs:67-71 */
 RT_HD void rt_sphere_uv(RtV3 p, double& u, double& v) {
@@ -437,7 +448,12 @@ RT_HD void rt_walk_exit(const RtSceneView& sc, RtWalk& k, uint32_t e) {
     const RtNode* nodes = sc.nodes;
     k.scope = nodes[e & ~RT_POP_FLAG].b;
     if (k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
-    else { k.cur = rt_ray_in_scope(nodes, k.scope, k.w); k.inv = rt_inv3(k.cur.d); }
+    else {
+        bool rotated;
+        k.cur = rt_ray_in_scope_r(nodes, k.scope, k.w, rotated);
+        k.inv = k.inv_w; /* Translate / FlipFace leave the direction alone: the same three quotients (hittable.rs:207-211) */
+        if (rotated) k.inv = rt_inv3(k.cur.d);
+    }
 }
 #ifndef RT_BRANCHLESS_PUSH
 #define RT_BRANCHLESS_PUSH 1

@@ -25,6 +25,9 @@ struct LdsNodes {
 #ifndef RT_SLICE_IDLE
 #define RT_SLICE_IDLE 48 /* stack walk: finished lanes of a wave that end a slice of the walk (0: every walk runs to its end) */
 #endif
+#ifndef RT_SLICE_TWO_STEPS
+#define RT_SLICE_TWO_STEPS(Cfg) (!Cfg::media)
+#endif
 /* counters[0] = next work item, counters[1] = traced segments */
 #ifndef RT_SWEEP_WAVES
 #define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
@@ -140,7 +143,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                     if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
                     /* a second step on the same vote where a step is cheap (measured: random_scene +1.8 %; final_scene, whose steps
                      * can be a whole medium, -4 %) */
-                    if constexpr (!Cfg::media) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
+                    if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
                 }
                 RT_STAMP(2);
                 if (rt_walk_done(k, stk)) {
