@@ -173,7 +173,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
 #define RT1W_GENERIC 8u   /* do not use a scene-specialised kernel even if the context has one (rt1w_context_specialise) */
-#define RT1W_WAVEFRONT 16u /* opt-in, big scenes (stack-walk variants) and the one-shot entries only: path state queued in HBM as SoA records, a vote-scheduled trace kernel + a shade kernel per bounce, a finish kernel for the tail (rt_wavefront.h); bit-identical to the default, measured 0.7-0.8x its speed.  Scenes that run a sweep kernel ignore the flag (stats.sorted bit 3 says what ran); rt1w_render_rows refuses it */
+#define RT1W_WAVEFRONT 16u /* opt-in, big scenes (stack-walk variants) and the one-shot entries only: path state queued in HBM as SoA records, a vote-scheduled trace kernel + a shade kernel per bounce, a finish kernel for the tail (rt_wavefront.h); bit-identical to the default, measured 0.5-0.6x its speed (0.7-0.8x before the default kernels' walk ran in slices).  Scenes that run a sweep kernel ignore the flag (stats.sorted bit 3 says what ran); rt1w_render_rows refuses it */
 #define RT1W_OUT_FRAME 32u /* rt1w_render only: `out_rgb` is the WHOLE image [height][width][3] (row 0 = j = 0) and the call writes just its tile's pixels at their image positions -- several contexts / processes fill one (shared, pinned) host frame: the host gather of the image-tiled multi-GPU job */
 #define RT1W_RNG_REFERENCE 64u /* PARITY MODE: draw from the reference's own generator instead of the Philox streams -- `StdRng::seed_from_u64(j * image_width + i)` (src/main.rs:964; ChaCha12, rand 0.8.4), one stream per pixel drawn on through all its samples in order (sample_offset must be 0, global_seed is ignored).  The frame is then the Rust program's own, pixel for pixel: the GPU reproduces rest_of_your_life.png.  Slower than the default (a lane owns a pixel for all its samples) */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering) */
