@@ -32,7 +32,11 @@ struct LdsNodes {
 #ifndef RT_SWEEP_WAVES
 #define RT_SWEEP_WAVES 3 /* waves per SIMD the register allocator must leave room for in the sweep variants */
 #endif
-#define RT_PLAIN_WAVES(Cfg, CACHE) (Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : (Cfg::sweep || CACHE ? 2 : 3))
+#ifndef RT_STACK_WAVES
+#define RT_STACK_WAVES 3 /* waves per SIMD the stack-walk kernels are built for.  Measured (random_scene / final_scene, Mpaths/s at 48 spp):
+                            2 waves (256 VGPRs, no spills) 559 / 171, 3 waves (168, spills in shading only) 662 / 188, 4 waves (128) 545 / 179 */
+#endif
+#define RT_PLAIN_WAVES(Cfg, CACHE) (Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : (Cfg::sweep || CACHE ? 2 : RT_STACK_WAVES))
 template <class Cfg, bool CACHE>
 __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
                                                      unsigned long long* __restrict__ counters) {
