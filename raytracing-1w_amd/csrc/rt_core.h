@@ -552,7 +552,7 @@ RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& r
     const uint32_t km = nd.kind & RT_KIND_MASK;
     RT_STAT_VISIT(km);
     /* the kinds are numbered so that each class is a range: the most frequent one costs one compare */
-    if (km <= RT_BVH1) rt_walk_box<Cfg, Cfg::media>(k, e, nd, stk); /* media scenes: boundary walks run with few lanes */
+    if (km <= RT_BVH1) rt_walk_box<Cfg, false>(k, e, nd, stk); /* the slab test without early exits (they paid while media boundaries were walked) */
     else if (km <= RT_YZ) rt_walk_leaf<Cfg>(sc, k, e, nd);
     else if (Cfg::scope_depth > 0 && km <= RT_FLIP) rt_walk_wrap(k, e, nd, stk); /* scope_depth 0: the scene has no wrapper node */
     else if (Cfg::media) rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
@@ -596,7 +596,7 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root,
                 const RtNodeHot nd = ns.hot(e);
                 const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
                 RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
-                if (cls == RT_WK_BOX) rt_walk_box<Cfg, Cfg::media>(k, e, nd, stk);
+                if (cls == RT_WK_BOX) rt_walk_box<Cfg, false>(k, e, nd, stk);
                 else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg>(sc, k, e, nd);
                 else if (cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk);
                 else parked = e;

@@ -23,7 +23,9 @@ struct LdsNodes {
 };
 
 #ifndef RT_SLICE_IDLE
-#define RT_SLICE_IDLE 48 /* stack walk: finished lanes of a wave that end a slice of the walk (0: every walk runs to its end) */
+/* stack walk: finished lanes of a wave that end a slice of the walk (0: every walk runs to its end).  Measured (Mpaths/s at 48 spp): media-free
+ * kernels (two steps per vote) 40: 636, 48: 662, 56: 675; media kernels 40: 190, 48: 191, 56: 189 */
+#define RT_SLICE_IDLE(Cfg) (Cfg::media ? 48 : 56)
 #endif
 #ifndef RT_SLICE_TWO_STEPS
 #define RT_SLICE_TWO_STEPS(Cfg) (!Cfg::media)
@@ -114,7 +116,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
             rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
             RT_STAMP(1);
         }
-        if constexpr (!Cfg::sweep && RT_SLICE_IDLE > 0 && RT_WALK_MODE == 0) {
+        if constexpr (!Cfg::sweep && RT_SLICE_IDLE(Cfg) > 0 && RT_WALK_MODE == 0) {
             /* ---- stack walk in slices ------------------------------------------------------------------------------
              * Walk lengths within a wave differ wildly (final_scene: 40 node visits per segment on average, several hundred
              * through the 1000-sphere cluster), and a wave that runs every walk to its end takes as long as its longest
@@ -140,7 +142,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }
                 RT_STAMP(7); /* bucket 7 here: rebuilding the walk's rays */
                 const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
-                const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE ? lanes_here - (uint32_t)RT_SLICE_IDLE : 0u;
+                const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE(Cfg) ? lanes_here - (uint32_t)RT_SLICE_IDLE(Cfg) : 0u;
                 for (;;) {
                     const bool more = !rt_walk_done(k, stk);
                     if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
