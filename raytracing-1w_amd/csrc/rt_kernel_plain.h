@@ -120,7 +120,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
             /* ---- stack walk in slices ------------------------------------------------------------------------------
              * Walk lengths within a wave differ wildly (final_scene: 40 node visits per segment on average, several hundred
              * through the 1000-sphere cluster), and a wave that runs every walk to its end takes as long as its longest
-             * lane: 122 wave-steps per segment against 40 (tools/walk_sim.cpp).  So the walk is suspended once RT_SLICE_IDLE (48; measured: 16 -13 %, 32 +3 %, 48 +7 %, 56 +6 %, 60 +4 % on random_scene / final_scene)
+             * lane: 122 wave-steps per segment against 40 (tools/walk_sim.cpp).  So the walk is suspended once RT_SLICE_IDLE(Cfg)
              * lanes have finished theirs: those lanes shade, start their next segment (or sample, or work item) and come
              * back with a fresh walk while the long walkers resume -- their stack is in LDS already, and the walk's rays are
              * rebuilt from the path's ray and the innermost wrapper by the operations that produced them (what leaving a
