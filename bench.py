@@ -4,16 +4,29 @@
 A "step" = one render of the workload INCLUDING the device->host gather (t_render covers kernel(s) +
 device->host gather; scene build/upload and PPM text excluded).  The scene and camera are resident in HBM before timing.
 
-  N = 1  BASELINE config C3: the reference's Cornell box (src/main.rs:395-512, lights :873-887, camera :888-892),
-         600x600, 1000 spp, depth 50, f64, into a pinned host frame (rt1w_render, RT1W_OUT_FRAME).
+Workloads (--workload; BASELINE.json configs, reference lines under /root/reference/src):
+  c3  (default; the configuration the metric is quoted on)  Cornell box main.rs:395-512, lights :873-887, camera :888-892,
+      600x600, 1000 spp, depth 50, `ray_color` with mixture-PDF light sampling (main.rs:51-116)
+  c2  random_scene main.rs:192-295, arm :816-827, 1200x800, 500 spp, `ray_color_without_light_objects` (main.rs:118-190)
+  c4  final_scene main.rs:635-795, arm :916-936, 800x800, 10 000 spp (the reference's own size; --spp to shorten)
+  c5  Cornell box 3840x2160 (16:9), --spp (default 1000; BASELINE names 10 000 = 22 s per step per GPU)
+
+  N = 1  one GPU renders the whole frame into a pinned host frame (rt1w_render, RT1W_OUT_FRAME).  The c3 line also carries
+         `other_configs`: C2 at full size and C4 at 400 spp measured the same way (D2H-inclusive Mpaths/s, kernel ms,
+         segments/path, roofline block), so every single-GPU BASELINE config has one driver-timed number.
   N > 1  the SAME job shape, image-tiled over the GPUs of one node as the north star says: 16-row strips dealt round-robin
          (sharding.interleaved_tile; one launch per GPU renders all of its strips), every rank's device->host copy writes
          its strips straight into ONE shared pinned host frame (sharding.SharedFrame) -- the host gather, inside the
          timed region.  No data-path collective; ranks share a barrier and a max-reduce of the elapsed time (gloo).
-         Weak scaling (task rule: independent units sharded across ranks): the frame grows with N at constant 1000 spp
-         and constant camera -- side = 16N*round(600*sqrt(N)/16N): 600, 864, 1216, 1664, a whole number of 16-row strips per GPU --
-         so every GPU keeps C3's 3.6e8 paths per step within 4 % and the per-pixel cost distribution of the Cornell view.  --strong keeps C3's 600x600 for all N.
-         --workload c5 is BASELINE config C5 (3840x2160, 16:9) at --spp (default 1000; 10 000 takes 22 s per step per GPU).
+         c3: weak scaling (task rule: independent units sharded across ranks): the frame grows with N at constant 1000 spp
+         and constant camera -- side = 16N*round(600*sqrt(N)/16N): 600, 864, 1216, 1664, a whole number of 16-row strips per
+         GPU -- so every GPU keeps C3's 3.6e8 paths per step within 4 %.  --strong keeps 600x600 for all N.
+         c2 / c4 / c5 are one fixed frame each (BASELINE: "tiled across 8 MI355X"): strong scaling.
+
+Launching.  `python bench.py --gpus N` with no launcher around it starts its own N rank processes (the replacement of rayon's
+all-core into_par_iter, main.rs:957-963): fresh children created BEFORE this process touches the GPU or imports torch,
+each given RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the parent relays rank 0's JSON line and exits
+non-zero if any child does.  Under `python -m torch.distributed.run` (WORLD_SIZE set by the launcher) it is one rank.
 
 `value` = whole-job paths / s over the timed steps, copy included.  The device-resident rate (framebuffer left in HBM)
 is reported as `value_device_resident`, never as `value`.
@@ -23,6 +36,7 @@ import importlib
 import json
 import math
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -31,19 +45,130 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-C3_W, C3_H, SPP, DEPTH = 600, 600, 1000, 50
+DEPTH = 50
 RECORD_BYTES = 128          # f64 SoA ray-state record
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
+WORKLOADS = {
+    "c2": dict(name="C2 random_scene", arm=0, W=1200, H=800, aspect=1.5, spp=500,
+               what="spheres-only BVH (MovingSphere + Sphere), lambertian/metal/dielectric, checker ground; BSDF sampling only"),
+    "c3": dict(name="C3 cornel_box", arm=5, W=600, H=600, aspect=1.0, spp=1000, what="mixture-PDF light sampling"),
+    "c4": dict(name="C4 final_scene", arm=7, W=800, H=800, aspect=1.0, spp=10000,
+               what="BVH of 400 boxes + 1000-sphere cluster under Translate(RotateY), Perlin + image textures, two constant_medium volumes"),
+    "c5": dict(name="C5 cornel_box 16:9", arm=5, W=3840, H=2160, aspect=16.0 / 9.0, spp=1000, what="mixture-PDF light sampling, 4K"),
+}
+OTHER_CONFIGS = (("c2", 500), ("c4", 400))   # carried by the N = 1 c3 line: (workload, spp)
 
-def cpu_baseline(width, height):
-    """Literal C++ restatement of the reference (oracle/oracle.cpp, kind 'port': the Rust crate cannot be built here --
-    no rustc/cargo), same scene/camera/size, all host cores (rayon's default, src/main.rs:957-963) AND one thread,
-    on a bounded spp (Mpaths/s does not depend on spp).  The only place bench.py touches oracle/."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc
-    sc = orc.OracleScene(5, build_seed=1, aspect_ratio=width / height)
-    # host cores this process may use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a share)
+
+# --------------------------------------------------------------------------------------------------------- launcher --
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, script=None, env_extra=None, timeout=None):
+    """Start `n` rank processes of `script` (default: this file) with `argv`, one per GPU, and wait for them.
+    Must be called from a process that has not initialised the GPU (nothing here imports torch or the HIP library);
+    the children are fresh interpreters (fork + exec of python before any GPU call -- never a re-exec of a process that
+    holds the GPU).  Returns (exit code, rank 0's stdout).  A failing rank ends the others."""
+    script = script or os.path.abspath(__file__)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RT1W_BENCH_PARENT=str(os.getpid()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    t_end = None if timeout is None else time.time() + timeout
+    rc = 0
+    out0 = None
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            p = procs[r]
+            if r == 0 and out0 is None and p.poll() is not None:
+                out0 = p.stdout.read().decode()
+            if p.poll() is not None:
+                live.discard(r)
+                if p.returncode != 0 and rc == 0:
+                    rc = p.returncode if p.returncode > 0 else 1
+                    print(f"bench.py: rank {r} exited with {p.returncode}; stopping the other ranks", file=sys.stderr)
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()   # the exact children started above, by pid
+        if t_end is not None and time.time() > t_end:
+            rc = rc or 124
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            break
+        time.sleep(0.05)
+    if out0 is None:
+        try:
+            out0 = procs[0].stdout.read().decode()
+        except Exception:
+            out0 = ""
+    for q in procs:
+        q.wait()
+    return rc, out0
+
+
+# ---------------------------------------------------------------------------------------------------------- backend --
+
+class GpuBackend:
+    """The product: librt1w.so through the ctypes binding.  No CPU fallback: without a GPU this raises."""
+    name = "hip"
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.rt = importlib.import_module("raytracing-1w_amd")          # oracle/ is only touched by cpu_baseline()
+        self.sharding = importlib.import_module("raytracing-1w_amd.sharding")
+
+    def check_device(self, local_rank):
+        assert self.torch.cuda.is_available() and self.rt.device_count() > local_rank, \
+            f"bench.py needs GPU {local_rank} (devices visible: {self.rt.device_count()}); there is no CPU fallback"
+        self.torch.cuda.set_device(local_rank)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def scene(self, arm, aspect, bvh, walk_order):
+        sc = self.rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
+        if bvh == "sah":
+            sc.set_bvh_build(True)
+        if walk_order == "near-far":
+            sc.set_walk_order(1)
+        return sc
+
+    def context(self, scene, dev):
+        return self.rt.Context(scene, dev)
+
+    def host_frame(self, H, W):
+        return self.rt.pinned_empty((H, W, 3))
+
+    def device_resident_ms(self, ctx, dev, W, H, spp, tile, strips, steps, kw):
+        out = self.torch.empty((tile[3], W, 3), dtype=self.torch.float64, device=f"cuda:{dev}")
+        self.torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            ctx.render_device(out.data_ptr(), W, H, spp, tile=tile, strips=strips, **kw)
+        self.torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / steps * 1e3
+
+
+# ------------------------------------------------------------------------------------------------------ CPU baseline --
+
+def host_cores():
+    """host cores this process may use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a share)"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -51,13 +176,24 @@ def cpu_baseline(width, height):
             cores = max(1, min(cores, int(int(quota) / int(period) + 0.5)))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(wl, width, height):
+    """Literal C++ restatement of the reference (oracle/oracle.cpp, kind 'port': the Rust crate cannot be built here --
+    no rustc/cargo), same scene/camera/size, all host cores (rayon's default, src/main.rs:957-963) AND one thread,
+    on a bounded spp (a sample of the same workload).  The only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    sc = orc.OracleScene(wl["arm"], build_seed=1, aspect_ratio=width / height)
+    cores = host_cores()
 
     def run(threads, budget_s):
-        spp = 2
+        spp = 1
         t0 = time.time()
         sc.render(width, height, spp, max_depth=DEPTH, threads=threads)
         dt = time.time() - t0
-        spp2 = max(2, min(512, int(spp * budget_s / max(dt, 1e-3))))
+        spp2 = max(1, min(512, int(spp * budget_s / max(dt, 1e-3))))
         t0 = time.time()
         _, st = sc.render(width, height, spp2, max_depth=DEPTH, threads=threads)
         dt = time.time() - t0
@@ -66,40 +202,116 @@ def cpu_baseline(width, height):
     v_all, spp_all, paths_all, dt_all = run(cores, 12.0)
     v_one, spp_one, paths_one, dt_one = run(1, 8.0)
     return {"value": round(v_all, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
-            "sample": f"cornell_box {width}x{height}, {spp_all} spp, depth {DEPTH} ({paths_all} paths in {dt_all:.1f} s on a "
+            "sample": f"{wl['name']} {width}x{height}, {spp_all} spp, depth {DEPTH} ({paths_all} paths in {dt_all:.1f} s on a "
                       f"std::thread pool of {cores} = the cores this job may use (affinity / cgroup quota; os.cpu_count() = {os.cpu_count()}); oracle built -O3)",
             "single_thread": {"value": round(v_one, 4), "cores": 1,
                               "sample": f"{spp_one} spp ({paths_one} paths in {dt_one:.1f} s)"}}
 
 
 def git_head():
+    """commit of the tree: `git rev-parse` where there is a repository, else the VERSION file build() wrote (the GPU box
+    receives the tree without .git)"""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "raytracing-1w_amd", "VERSION")).read().split()[0]
     except Exception:
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--generic", action="store_true", help="ablation: the generic kernel instead of the scene-specialised one")
-    ap.add_argument("--spp", type=int, default=SPP, help="the contract workload is 1000")
-    ap.add_argument("--workload", choices=("c3", "c5"), default="c3")
-    ap.add_argument("--strong", action="store_true", help="N > 1: keep the N = 1 frame (strong scaling of one job)")
-    ap.add_argument("--all-ranks-on-device", type=int, default=None,
-                    help="rehearsal only (1-GPU box): every rank uses this device instead of LOCAL_RANK")
-    ap.add_argument("--check-frame", action="store_true",
-                    help="after timing, rank 0 renders the whole frame alone and requires the gathered frame to be bit-identical")
-    a = ap.parse_args()
+def stored_pmc(workload, kernel, spec_key):
+    """Stored PMC figures (separate rocprofv3 --pmc passes, profiles/pmc_summary.json), attached only when they were taken on
+    the kernel that just ran.  valu_lane_issue_frac = VALU-busy fraction of the SIMD cycles x active lanes per VALU
+    instruction / 64: the share of the f64 VALU lane-issue capacity doing work -- the kernel's true limiter."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        ent = json.load(open(p)).get(workload)
+    except Exception:
+        return None
+    if not ent:
+        return None
+    same = ent.get("kernel") == kernel and (ent.get("specialise_key") in (None, spec_key))
+    ent = dict(ent, matches_this_run=bool(same), file="profiles/pmc_summary.json")
+    return ent
 
+
+def kernel_name(st):
+    flags = st.get("sorted", 0)
+    if flags & 4:
+        return "rt_jit_sorted"
+    return ("rt_render_kernel_sorted<V%d>" if (flags & 1) else "rt_render_kernel<V%d>") % st["variant"]
+
+
+def roofline_block(workload, st, kernel_ms, pixels, spec_key):
+    """roofline of the dominant kernel: algorithmic bytes per launch = 2 * 128 B per traced segment (ray-state record read +
+    written once per segment) + 24 B per pixel; duration from HIP events on the kernel's own stream"""
+    segs = st["segments"]
+    algo_bytes = 2 * RECORD_BYTES * segs + 24 * pixels
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    kernel = kernel_name(st)
+    pmc = stored_pmc(workload, kernel, spec_key)
+    ok = bool(pmc and pmc["matches_this_run"])
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc.get("hbm_bytes_per_launch") if ok else None,
+            "valu_lane_issue_frac": pmc.get("valu_lane_issue_frac") if ok else None,
+            "pmc_source": pmc,
+            "kernel": kernel, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
+            "true_limiter": "f64 VALU issue + lane divergence (valu_lane_issue_frac): the ray state stays in VGPRs, so measured HBM "
+                            "traffic is far below the algorithmic record traffic the graded `frac` counts"}
+
+
+# ------------------------------------------------------------------------------------------------------------ ranks --
+
+def measure_single(be, dev, key, spp, steps, warmup, bvh, walk_order, generic=False):
+    """One single-GPU workload measured like `value`: whole frame into a pinned host frame, wall clock over `steps` renders."""
+    wl = WORKLOADS[key]
+    W, H = wl["W"], wl["H"]
+    scene = be.scene(wl["arm"], wl["aspect"], bvh, walk_order)
+    ctx = be.context(scene, dev)
+    spec = None
+    try:
+        spec = ctx.specialise()
+    except Exception:
+        spec = None
+    host = be.host_frame(H, W)
+    kw = dict(max_depth=DEPTH, generic=generic)
+    for _ in range(warmup):
+        ctx.render(W, H, spp, frame=host, **kw)
+    be.synchronize()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(steps):
+        _, st = ctx.render(W, H, spp, frame=host, **kw)
+        kms.append(st["kernel_ms"])
+    be.synchronize()
+    dt = time.perf_counter() - t0
+    paths = W * H * spp
+    kernel_ms = sum(kms) / len(kms)
+    out = {"workload": f"{wl['name']} (scene arm {wl['arm']}) {W}x{H}, {spp} spp, depth {DEPTH}; {wl['what']}",
+           "value": round(paths * steps / dt / 1e6, 2), "unit": "Mpaths/s (kernels + device->host copy)", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 3),
+           "value_kernel_only": round(paths / kernel_ms / 1e3, 2),
+           "paths_per_step": paths, "segments_per_path": round(st["segments"] / paths, 4),
+           "scene_nodes": scene.info()["n_nodes"], "bvh": bvh_label(bvh, walk_order), "dtype": "f64",
+           "roofline": roofline_block(key, st, kernel_ms, W * H, spec.get("key") if spec else None)}
+    ctx.close()
+    return out
+
+
+def bvh_label(bvh, walk_order):
+    tree = ("the reference's build (BVHNode::new, bvh.rs:54-103: random axis, median split; build_seed 1)" if bvh == "reference"
+            else "SAH rebuild of the same leaf sets (rt1w_scene_set_bvh_build; opt-in, statistical parity on entropy-seeded arms)")
+    order = "left-then-right (bvh.rs:38-47)" if walk_order == "reference" else "near child first where result-preserving (rt1w_scene_set_walk_order)"
+    return f"{tree}; walk order {order}"
+
+
+def rank_main(a, be=None):
+    """One rank of the job (or the whole job at N = 1)."""
     import numpy as np
-    import torch
-    rt = importlib.import_module("raytracing-1w_amd")          # the product; oracle/ is only touched by cpu_baseline()
-    sharding = importlib.import_module("raytracing-1w_amd.sharding")
-
+    be = be or GpuBackend()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,23 +324,27 @@ def main():
 
     if a.all_ranks_on_device is not None:
         local_rank = a.all_ranks_on_device
-    assert torch.cuda.is_available() and rt.device_count() > local_rank, "bench.py needs the GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    be.check_device(local_rank)
+    rt, sharding = be.rt, be.sharding
 
-    if a.workload == "c5":
-        W, H, aspect, name = 3840, 2160, 16.0 / 9.0, "C5 cornel_box 16:9"
-        if world > 1 and not a.strong:
-            a.strong = True                                              # C5 is one fixed frame
-    else:
+    wl = WORKLOADS[a.workload]
+    spp = a.spp if a.spp else wl["spp"]
+    if a.workload == "c3":
         # weak scaling: ~C3's paths per GPU, and a side that is a multiple of 16 * N rows so that every GPU owns the same number of
         # 16-row strips (N = 2, 4, 8: 864, 1216, 1664)
-        side = C3_W if (a.strong or world == 1) else 16 * world * max(1, round(C3_W * math.sqrt(world) / (16 * world)))
-        W, H, aspect, name = side, side, 1.0, "C3 cornel_box"
-    spp = a.spp
-    scene = rt.Scene.reference(5, build_seed=1, aspect_ratio=aspect)
-    ctx = rt.Context(scene, local_rank)
+        side = wl["W"] if (a.strong or world == 1) else 16 * world * max(1, round(wl["W"] * math.sqrt(world) / (16 * world)))
+        W, H = side, side
+    else:
+        W, H = wl["W"], wl["H"]
+        if world > 1:
+            a.strong = True                                              # one fixed frame, tiled
+    if a.width and a.height:                                             # rehearsals / tests only
+        W, H = a.width, a.height
+    scene = be.scene(wl["arm"], W / H, a.bvh, a.walk_order)
+    ctx = be.context(scene, local_rank)
     # kernel specialised for this scene's topology: from the kernel cache the build fills (raytracing-1w_amd/kernels), or compiled
-    # here with hiprtc (3-5 s, outside the timed region like the rest of the set-up); --generic keeps the generic kernel
+    # here with hiprtc (3-5 s, outside the timed region like the rest of the set-up); --generic keeps the generic kernel;
+    # scenes of more than 256 nodes (c2, c4) have no such kernel and run the stack-walk variants
     spec = None
     if not a.generic:
         try:
@@ -137,8 +353,9 @@ def main():
             spec = {"active": False, "error": str(e)}
 
     # the whole-image host frame every rank's copy lands in
-    shm_name = f"rt1w_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}"
+    frame = None
     if world > 1:
+        shm_name = f"rt1w_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('RT1W_BENCH_PARENT', os.getppid())}"
         if rank == 0:
             frame = sharding.SharedFrame(shm_name, W, H, True, rt)
         dist.barrier()
@@ -146,8 +363,7 @@ def main():
             frame = sharding.SharedFrame(shm_name, W, H, False, rt)
         host = frame.array
     else:
-        frame = None
-        host = rt.pinned_empty((H, W, 3))
+        host = be.host_frame(H, W)
     y0, rows, srows, period = sharding.interleaved_tile(H, world, rank)
     chunk = rt.default_chunk(W, H, spp)                                  # the whole frame's chunking: same sums as one GPU
     kw = dict(max_depth=DEPTH, generic=a.generic, chunk=chunk)
@@ -162,113 +378,132 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    segs = 0
-    st = None
-    for _ in range(a.steps):
-        st = step()
-        if st is not None:
-            kernel_ms.append(st["kernel_ms"])
-            segs = st["segments"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    seg_total = segs
-    if dist is not None:
-        t = torch.tensor([elapsed, float(segs)], dtype=torch.float64)
-        tm = t.clone()
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tm[0])
-        seg_total = int(t[1])
-
-    paths_per_step = W * H * spp
-    value = paths_per_step * a.steps / elapsed / 1e6
-
-    frame_check = None
-    if a.check_frame:
+    try:
+        for _ in range(a.warmup):
+            step()
         barrier()
-        if rank == 0:
-            solo, _ = ctx.render(W, H, spp, **kw)
-            frame_check = bool(np.array_equal(solo, host, equal_nan=True))
-            assert frame_check, "gathered frame differs from the single-GPU frame"
-
-    # device-resident rate of this rank's share (framebuffer left in HBM), outside the timed region
-    dev_ms = None
-    if rows:
-        out = torch.empty((rows, W, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(max(1, min(a.steps, 3))):
-            ctx.render_device(out.data_ptr(), W, H, spp, tile=tile, strips=(srows, period), **kw)
-        torch.cuda.synchronize()
-        dev_ms = (time.perf_counter() - t1) / max(1, min(a.steps, 3)) * 1e3
-
-    if rank == 0:
-        # roofline of the dominant kernel: algorithmic bytes per launch = 2 * 128 B per traced segment (ray-state record
-        # read + written once per segment) + 24 B per pixel; HIP events on the kernel's own stream
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        my_pixels = rows * W
-        algo_bytes = 2 * RECORD_BYTES * segs + 24 * my_pixels
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        flags = st.get("sorted", 0)
-        kernel = "rt_jit_sorted" if (flags & 4) else ("rt_render_kernel_sorted<V%d>" % st["variant"] if (flags & 1) else "rt_render_kernel<V%d>" % st["variant"])
-        # HBM traffic from the PMC counters is a STORED measurement (separate rocprofv3 --pmc passes, profiles/): it is only
-        # attached when it was taken on this very kernel (same specialisation key), and carries the commit it was taken at
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                prof = json.load(open(tp))
-                same = bool(spec) and prof.get("specialise_key") == spec.get("key") and world == 1 and a.workload == "c3" and spp == SPP
-                traffic_src = {"file": "profiles/hbm_traffic.json", "measured_at_commit": prof.get("commit"),
-                               "kernel_key": prof.get("specialise_key"), "matches_this_run": same, "pmc": prof.get("pmc") if same else None}
-                if same:
-                    traffic = prof.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-        line = {
-            "metric": "Mpaths/s", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong" if (a.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (procedural Cornell box of the reference, build_seed 1; no external data)",
-            "config": {"workload": f"{name} (scene arm 5) {W}x{H}, {spp} spp, depth {DEPTH}, mixture-PDF light sampling; "
-                                   f"timed region = kernels + device->host gather into one pinned host frame",
-                       "width": W, "height": H, "spp": spp, "max_depth": DEPTH,
-                       "paths_per_step": paths_per_step, "segments_per_path": round(seg_total / paths_per_step, 4),
-                       "chunk": st["chunk"], "n_chunks": st["n_chunks"], "grid": st["grid"], "block": st["block"],
-                       "kernel_variant": st["variant"], "workgroup_path_sort": bool(flags & 1),
-                       "scene_specialised_kernel": bool(flags & 4), "specialise": spec,
-                       "parallelism": (f"image-tiled x{world}: 16-row strips round-robin, one launch per GPU, every GPU's D2H writes its "
-                                       f"strips into one shared pinned host frame (host gather, no collective)") if world > 1
-                                      else "1 GPU, D2H into a pinned host frame",
-                       "host_frame_pinned": bool(frame._pinned) if frame is not None else True,
-                       "commit": git_head()},
-            "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel, "kernel_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
-                         "true_limiter": "f64 VALU issue + lane divergence: the ray state stays in VGPRs, so measured HBM "
-                                         "traffic is ~600x below the algorithmic record traffic the graded roofline counts"},
-        }
-        if frame_check is not None:
-            line["gathered_frame_equals_single_gpu_frame"] = frame_check
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(W, H)
-        print(json.dumps(line), flush=True)
-    ctx.close()
-    if frame is not None:
+        t0 = time.perf_counter()
+        kernel_ms = []
+        segs = 0
+        st = None
+        for _ in range(a.steps):
+            st = step()
+            if st is not None:
+                kernel_ms.append(st["kernel_ms"])
+                segs = st["segments"]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        seg_total = segs
         if dist is not None:
-            dist.barrier()
-        frame.close()
+            import torch
+            t = torch.tensor([elapsed, float(segs)], dtype=torch.float64)
+            tm = t.clone()
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            elapsed = float(tm[0])
+            seg_total = int(t[1])
+
+        paths_per_step = W * H * spp
+        value = paths_per_step * a.steps / elapsed / 1e6
+
+        frame_check = None
+        if a.check_frame:
+            barrier()
+            if rank == 0:
+                solo, _ = ctx.render(W, H, spp, **kw)
+                frame_check = bool(np.array_equal(solo, host, equal_nan=True))
+                assert frame_check, "gathered frame differs from the single-GPU frame"
+
+        # device-resident rate of this rank's share (framebuffer left in HBM), outside the timed region
+        dev_ms = None
+        if rows and hasattr(be, "device_resident_ms"):
+            dev_ms = be.device_resident_ms(ctx, local_rank, W, H, spp, tile, (srows, period), max(1, min(a.steps, 3)), kw)
+
+        if rank == 0:
+            avg_ms = sum(kernel_ms) / len(kernel_ms)
+            my_pixels = rows * W
+            flags = st.get("sorted", 0)
+            line = {
+                "metric": "Mpaths/s", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong" if (a.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64",
+                "data": f"synthetic (the reference's procedural scene arm {wl['arm']}, build_seed 1"
+                        + ("; assets/earthmap.jpg as the image texture" if wl["arm"] == 7 else "; no external data") + ")",
+                "config": {"workload": f"{wl['name']} (scene arm {wl['arm']}) {W}x{H}, {spp} spp, depth {DEPTH}, {wl['what']}; "
+                                       f"timed region = kernels + device->host gather into one pinned host frame",
+                           "width": W, "height": H, "spp": spp, "max_depth": DEPTH,
+                           "paths_per_step": paths_per_step, "segments_per_path": round(seg_total / paths_per_step, 4),
+                           "chunk": st["chunk"], "n_chunks": st["n_chunks"], "grid": st["grid"], "block": st["block"],
+                           "kernel_variant": st["variant"], "workgroup_path_sort": bool(flags & 1),
+                           "scene_specialised_kernel": bool(flags & 4), "specialise": spec,
+                           "scene_nodes": scene.info()["n_nodes"], "bvh": bvh_label(a.bvh, a.walk_order),
+                           "parallelism": (f"image-tiled x{world}: 16-row strips round-robin, one launch per GPU, every GPU's D2H writes its "
+                                           f"strips into one shared pinned host frame (host gather, no collective); ranks started by "
+                                           + ("bench.py itself" if os.environ.get("RT1W_BENCH_PARENT") else "the outer launcher")) if world > 1
+                                          else "1 GPU, D2H into a pinned host frame",
+                           "host_frame_pinned": bool(frame._pinned) if frame is not None else True,
+                           "host_frame_pin_error": getattr(frame, "pin_error", None) if frame is not None else None,
+                           "backend": be.name, "commit": git_head()},
+                "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
+                "roofline": roofline_block(a.workload if (spp == wl["spp"] and world == 1) else None, st, avg_ms, my_pixels,
+                                           spec.get("key") if spec else None),
+            }
+            if frame_check is not None:
+                line["gathered_frame_equals_single_gpu_frame"] = frame_check
+            if world == 1 and a.workload == "c3" and not a.no_other_configs and not (a.width and a.height):
+                line["other_configs"] = {k: measure_single(be, local_rank, k, s, 3, 1, a.bvh, a.walk_order) for k, s in OTHER_CONFIGS}
+            if world == 1 and not a.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(wl, W, H)
+            print(json.dumps(line), flush=True)
+    finally:
+        ctx.close()
+        if frame is not None:
+            try:
+                if dist is not None:
+                    dist.barrier()
+            finally:
+                frame.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1, c3: skip the C2 / C4 entries of the line")
+    ap.add_argument("--generic", action="store_true", help="ablation: the generic kernel instead of the scene-specialised one")
+    ap.add_argument("--spp", type=int, default=0, help="default: the workload's own (c3 1000, c2 500, c4 10000, c5 1000)")
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="c3")
+    ap.add_argument("--bvh", choices=("reference", "sah"), default="reference", help="which tree the big scenes are walked on")
+    ap.add_argument("--walk-order", choices=("reference", "near-far"), default="reference")
+    ap.add_argument("--strong", action="store_true", help="N > 1, c3: keep the N = 1 frame (strong scaling of one job)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="rehearsal only (1-GPU box): every rank uses this device instead of LOCAL_RANK")
+    ap.add_argument("--check-frame", action="store_true",
+                    help="after timing, rank 0 renders the whole frame alone and requires the gathered frame to be bit-identical")
+    ap.add_argument("--width", type=int, default=0, help="tests / rehearsals only: override the frame")
+    ap.add_argument("--height", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def main(argv=None, backend_factory=None, script=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks ourselves.  Nothing above imported torch or the HIP library.
+        rc, out0 = launch_ranks(a.gpus, argv, script=script)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
+            rc = 1
+        sys.exit(rc)
+    rank_main(a, backend_factory() if backend_factory else None)
 
 
 if __name__ == "__main__":

@@ -50,28 +50,55 @@ class SharedFrame:
     nothing is stitched afterwards.  Rank 0 creates, the others attach after a barrier; rank 0 unlinks."""
 
     def __init__(self, name, width, height, create, rt=None):
+        import atexit
         import mmap
         import os
         self.path = os.path.join("/dev/shm", name)
         self.nbytes = width * height * 3 * 8
         self.created = create
-        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
-        fd = os.open(self.path, flags, 0o600)
+        self.pin_error = None
+        nofollow = getattr(os, "O_NOFOLLOW", 0)
+        if create:
+            # never follow or truncate something planted under this name: a stale regular file of OUR OWN (a rank that died) is
+            # removed first, then the segment is created exclusively
+            try:
+                st = os.lstat(self.path)
+                import stat
+                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid():
+                    os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            fd = os.open(self.path, os.O_RDWR | os.O_CREAT | os.O_EXCL | nofollow, 0o600)
+            atexit.register(self._unlink)          # the creator removes the segment even when it dies on an assert
+        else:
+            fd = os.open(self.path, os.O_RDWR | nofollow)
         try:
             if create:
                 os.ftruncate(fd, self.nbytes)
+            elif os.fstat(fd).st_size != self.nbytes:
+                raise ValueError(f"{self.path}: {os.fstat(fd).st_size} bytes, expected {self.nbytes}")
             self._mm = mmap.mmap(fd, self.nbytes)
         finally:
             os.close(fd)
         self.array = np.frombuffer(self._mm, dtype=np.float64).reshape(height, width, 3)
         self._rt = rt
         self._pinned = False
-        if rt is not None:
+        if rt is not None and hasattr(rt, "host_register"):
             try:   # pinning is an optimisation (full-rate, asynchronous device->host copies); a pageable frame works too
                 rt.host_register(self.array)
                 self._pinned = True
-            except Exception:
+            except Exception as e:
                 self._pinned = False
+                self.pin_error = str(e)            # reported by bench.py (config.host_frame_pin_error)
+
+    def _unlink(self):
+        import os
+        if self.created:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            self.created = False
 
     def close(self):
         if self._pinned:
@@ -85,12 +112,7 @@ class SharedFrame:
             self._mm.close()
         except BufferError:
             pass
-        if self.created:
-            import os
-            try:
-                os.unlink(self.path)
-            except FileNotFoundError:
-                pass
+        self._unlink()
 
 
 def sample_range(spp_total, world_size, rank):

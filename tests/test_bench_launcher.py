@@ -1,0 +1,67 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` with NO launcher around it must start its own N ranks
+(it died at the WORLD_SIZE assert).  The N-rank control flow -- rendezvous on 127.0.0.1, interleaved tiles, one
+shared host frame, max-over-ranks clock, --check-frame -- is exercised here on the CPU with the CPU build of the kernel core
+injected as the renderer (tests/bench_cpu_ranks.py); the GPU tier runs the real thing (test_gpu_parity.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import orc
+
+ROOT = orc.ROOT
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_bench_starts_its_own_two_ranks_and_gathers_one_frame(rt):
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_ranks.py"), "--gpus", "2", "--width", "48", "--height", "48",
+           "--spp", "4", "--steps", "1", "--warmup", "0", "--check-frame", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["backend"] == "cpu-core (test)"
+    assert line["gathered_frame_equals_single_gpu_frame"] is True
+    assert "bench.py itself" in line["config"]["parallelism"]
+    assert line["config"]["width"] == 48 and line["config"]["paths_per_step"] == 48 * 48 * 4
+    for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "roofline"):
+        assert k in line
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt1w_bench_")]   # the shared frame was removed
+
+
+def test_bench_three_ranks_with_a_ragged_last_strip(rt):
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_ranks.py"), "--gpus", "3", "--width", "40", "--height", "56",
+           "--spp", "2", "--steps", "1", "--warmup", "1", "--check-frame", "--no-cpu-baseline", "--workload", "c2"]
+    p = subprocess.run(cmd, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["gathered_frame_equals_single_gpu_frame"] is True
+
+
+def test_product_bench_fails_loudly_without_a_gpu(rt):
+    """the real bench.py has no CPU path: on a box without a GPU every rank dies on the device check and the parent's exit
+    code says so (no JSON line)"""
+    if rt.device_count() > 0:
+        import pytest
+        pytest.skip("this check is for the CPU-only container")
+    for gpus in ("1", "2"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                           env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0
+        assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_launcher_parent_never_touches_the_gpu_stack():
+    """the parent process of `--gpus N` must not import torch or load librt1w.so before it forks its ranks"""
+    code = ("import sys; sys.argv=['bench.py','--gpus','2']; import bench; "
+            "bench.launch_ranks = lambda n, argv, script=None: (print('MODS', 'torch' in sys.modules, "
+            "any('raytracing' in m for m in sys.modules)) or (0, '{}\\n')); bench.main()")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    assert "MODS False False" in p.stdout.decode()
