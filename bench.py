@@ -320,7 +320,16 @@ def rank_main(a, be=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: barrier + max(time)
+        # gloo's C++ side prints its "connected to N peer ranks" note on stdout: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: barrier + max(time)
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if a.all_ranks_on_device is not None:
         local_rank = a.all_ranks_on_device
@@ -498,6 +507,7 @@ def main(argv=None, backend_factory=None, script=None):
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: start the N ranks ourselves.  Nothing above imported torch or the HIP library.
         rc, out0 = launch_ranks(a.gpus, argv, script=script)
+        out0 = "".join(l + "\n" for l in out0.splitlines() if l.startswith("{"))   # rank 0's JSON line, nothing else
         sys.stdout.write(out0)
         sys.stdout.flush()
         if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
