@@ -13,7 +13,8 @@ Workloads (--workload; BASELINE.json configs, reference lines under /root/refere
 
   N = 1  one GPU renders the whole frame into a pinned host frame (rt1w_render, RT1W_OUT_FRAME).  The c3 line also carries
          `other_configs`: C2 at full size and C4 at 400 spp measured the same way (D2H-inclusive Mpaths/s, kernel ms,
-         segments/path, roofline block), so every single-GPU BASELINE config has one driver-timed number.
+         segments/path, roofline block), on the reference's trees (c2, c4) and on the opt-in SAH trees with near-far
+         order (c2_sah, c4_sah), so every single-GPU BASELINE config has one driver-timed number per tree.
   N > 1  the SAME job shape, image-tiled over the GPUs of one node as the north star says: 16-row strips dealt round-robin
          (sharding.interleaved_tile; one launch per GPU renders all of its strips), every rank's device->host copy writes
          its strips straight into ONE shared pinned host frame (sharding.SharedFrame) -- the host gather, inside the
@@ -57,7 +58,10 @@ WORKLOADS = {
                what="BVH of 400 boxes + 1000-sphere cluster under Translate(RotateY), Perlin + image textures, two constant_medium volumes"),
     "c5": dict(name="C5 cornel_box 16:9", arm=5, W=3840, H=2160, aspect=16.0 / 9.0, spp=1000, what="mixture-PDF light sampling, 4K"),
 }
-OTHER_CONFIGS = (("c2", 500), ("c4", 400))   # carried by the N = 1 c3 line: (workload, spp)
+# carried by the N = 1 c3 line: (entry, workload, spp, bvh, walk order).  The *_sah entries run the opt-in SAH trees (checked against the
+# literal oracle on the same topology, tests/test_bvh_build.py) with the near child first where that preserves the result
+OTHER_CONFIGS = (("c2", "c2", 500, "reference", "reference"), ("c4", "c4", 400, "reference", "reference"),
+                 ("c2_sah", "c2", 500, "sah", "near-far"), ("c4_sah", "c4", 400, "sah", "near-far"))
 
 
 # --------------------------------------------------------------------------------------------------------- launcher --
@@ -462,7 +466,8 @@ def rank_main(a, be=None):
             if frame_check is not None:
                 line["gathered_frame_equals_single_gpu_frame"] = frame_check
             if world == 1 and a.workload == "c3" and not a.no_other_configs and not (a.width and a.height):
-                line["other_configs"] = {k: measure_single(be, local_rank, k, s, 3, 1, a.bvh, a.walk_order) for k, s in OTHER_CONFIGS}
+                line["other_configs"] = {name: measure_single(be, local_rank, k, s, 3, 1, bvh, order)
+                                         for name, k, s, bvh, order in OTHER_CONFIGS}
             if world == 1 and not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(wl, W, H)
             print(json.dumps(line), flush=True)

@@ -146,6 +146,14 @@ int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode);
 #define RT1W_BVH_REFERENCE 0u
 #define RT1W_BVH_SAH 1u
 int rt1w_scene_set_bvh_build(rt1w_scene* s, uint32_t mode);
+/* The trees RT1W_BVH_SAH built in place of `BVHNode::new` (src/bvh.rs:54-103), written down so that they can be checked from
+ * outside (tests feed them to the literal oracle, which then runs `BVHNode::hit` src/bvh.rs:25-50 over the same trees).
+ * One stream of int32 for the whole scene, the rebuilt BVHs in the order the flattener meets them (depth first): each tree in
+ * pre-order, -1 = an inner node (`BVHChild::Two`, its two subtrees follow), k >= 0 = the k-th leaf of that BVH counted left to
+ * right through the tree `BVHNode::new` had built (nested BVHNodes are merged into their parent's leaf set); what a leaf holds
+ * inside (an AABox's side BVH, a wrapped BVH, a medium's boundary) follows right after the leaf's number.  Returns the number
+ * of entries (0 under RT1W_BVH_REFERENCE); `out` may be NULL to ask for the size. */
+int64_t rt1w_scene_get_bvh_topology(const rt1w_scene* s, int32_t* out, uint64_t capacity);
 
 /* introspection of the committed flat scene (tests, DESIGN.md numbers) */
 typedef struct rt1w_scene_info {

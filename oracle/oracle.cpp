@@ -603,6 +603,7 @@ static uint64_t float_ord_key(Float x) { /* float-ord 0.3.1: total order on bits
 struct BVHNode : Hittable {
     HBox left, right; /* BVHChild::One(obj) -> left only */
     AABB aabb;
+    Float time0 = 0.0, time1 = 1.0; /* what `new` was called with (kept for orc_scene_apply_topology only) */
     bool bounding_box(Float, Float, AABB& out) const override { out = aabb; return true; } /* :21-23 */
     bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override { /* :25-50 */
         if (!aabb.hit(ray, t_min, t_max)) return false;
@@ -619,6 +620,7 @@ struct BVHNode : Hittable {
     /* BVHNode::new bvh.rs:54-103; throws std::string on the reference's panics */
     static std::unique_ptr<BVHNode> make(std::vector<HBox> objects, Float time0, Float time1, MyRng& rng) {
         std::unique_ptr<BVHNode> n(new BVHNode());
+        n->time0 = time0; n->time1 = time1;
         size_t len = objects.size();
         if (len == 0) throw std::string("objects mut not be empty");
         if (len == 1) {
@@ -1276,6 +1278,82 @@ orc_scene* orcb_finish(orc_builder* b) {
     o->keep_mats = b->mat; o->keep_tex = b->tex;
     delete b;
     return o;
+}
+
+/* ---- TEST SUPPORT with no counterpart in the reference: BVHs over the same leaf sets with a tree given from outside ----
+ * The product's opt-in SAH build (rt1w_scene_set_bvh_build) replaces BVHNode::new (bvh.rs:54-103) by another tree over the same
+ * leaves.  To check it against THIS restatement, the trees are handed over as a topology stream (format: include/rt1w.h,
+ * rt1w_scene_get_bvh_topology) and rebuilt here as ordinary BVHNodes: children as the stream says, `aabb` =
+ * surrounding_box of the two children's bounding boxes (what bvh.rs:76-78,97-99 compute), and then the literal
+ * `BVHNode::hit` (bvh.rs:25-50) above walks them -- nothing of the product's traversal is involved. */
+struct TopoReader {
+    const int32_t* p; uint64_t n, pos; bool ok;
+    int32_t next() { if (pos >= n) { ok = false; return 0; } return p[pos++]; }
+};
+static size_t count_leaves(const Hittable* h) {
+    const BVHNode* b = dynamic_cast<const BVHNode*>(h);
+    if (!b) return 1;
+    return count_leaves(b->left.get()) + (b->right ? count_leaves(b->right.get()) : 0);
+}
+static void take_leaves(HBox& h, std::vector<HBox>& out) { /* left to right through nested BVHNodes */
+    BVHNode* b = dynamic_cast<BVHNode*>(h.get());
+    if (!b) { out.push_back(std::move(h)); return; }
+    take_leaves(b->left, out);
+    if (b->right) take_leaves(b->right, out);
+}
+static void retopo_any(HBox& h, TopoReader& r);
+static HBox build_from_topology(std::vector<HBox>& leaves, TopoReader& r, Float t0, Float t1) {
+    const int32_t code = r.next();
+    if (!r.ok) return HBox();
+    if (code >= 0) {
+        if ((size_t)code >= leaves.size() || !leaves[(size_t)code]) { r.ok = false; return HBox(); }
+        HBox leaf = std::move(leaves[(size_t)code]);
+        retopo_any(leaf, r); /* what the leaf holds inside follows its number */
+        return leaf;
+    }
+    std::unique_ptr<BVHNode> n(new BVHNode());
+    n->time0 = t0; n->time1 = t1;
+    n->left = build_from_topology(leaves, r, t0, t1);
+    n->right = build_from_topology(leaves, r, t0, t1);
+    if (!r.ok || !n->left || !n->right) { r.ok = false; return HBox(); }
+    AABB lb, rb;
+    if (!n->left->bounding_box(t0, t1, lb) || !n->right->bounding_box(t0, t1, rb)) { r.ok = false; return HBox(); }
+    n->aabb = surrounding_box(lb, rb);
+    return HBox(n.release());
+}
+static void retopo_any(HBox& h, TopoReader& r) {
+    if (!r.ok || !h) return;
+    if (BVHNode* b = dynamic_cast<BVHNode*>(h.get())) {
+        if (count_leaves(b) >= 2) {
+            const Float t0 = b->time0, t1 = b->time1;
+            std::vector<HBox> leaves;
+            take_leaves(h, leaves);
+            h = build_from_topology(leaves, r, t0, t1);
+            for (const HBox& l : leaves) if (l) r.ok = false; /* every leaf must have been placed */
+        } else { /* a chain of BVHChild::One down to a single object: kept as built */
+            while (BVHNode* c = dynamic_cast<BVHNode*>(b->left.get())) b = c;
+            retopo_any(b->left, r);
+        }
+        return;
+    }
+    if (AABox* a = dynamic_cast<AABox*>(h.get())) {
+        HBox sides(a->sides.release());
+        retopo_any(sides, r);
+        a->sides.reset(dynamic_cast<BVHNode*>(sides.get()));
+        if (a->sides) sides.release(); else r.ok = false;
+    } else if (Translate* t = dynamic_cast<Translate*>(h.get())) retopo_any(t->hittable, r);
+    else if (RotateY* ry = dynamic_cast<RotateY*>(h.get())) retopo_any(ry->hittable, r);
+    else if (FlipFace* f = dynamic_cast<FlipFace*>(h.get())) retopo_any(f->inner, r);
+    else if (ConstantMedium* m = dynamic_cast<ConstantMedium*>(h.get())) retopo_any(m->boundary, r);
+}
+/* 0 = done; -1 = the stream does not fit this scene (the scene is unusable afterwards) */
+int orc_scene_apply_topology(orc_scene* o, const int32_t* topo, uint64_t n) {
+    TopoReader r{topo, n, 0, true};
+    HBox world(o->s.world.release());
+    retopo_any(world, r);
+    o->s.world.reset(dynamic_cast<BVHNode*>(world.get()));
+    if (o->s.world) world.release(); else r.ok = false;
+    return (r.ok && r.pos == n) ? 0 : -1;
 }
 
 /* ---- leaf entry points for known-answer tests ---- */

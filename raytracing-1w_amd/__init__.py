@@ -118,6 +118,7 @@ _sig("rt1w_scene_build_reference", C.c_int, C.c_int, C.c_uint64, C.c_double, _P,
      C.POINTER(_P), C.POINTER(C.c_uint32 * 3))
 _sig("rt1w_scene_set_walk_order", C.c_int, _P, C.c_uint32)
 _sig("rt1w_scene_set_bvh_build", C.c_int, _P, C.c_uint32)
+_sig("rt1w_scene_get_bvh_topology", C.c_int64, _P, _P, C.c_uint64)
 _sig("rt1w_scene_get_info", C.c_int, _P, C.POINTER(SceneInfo))
 _sig("rt1w_scene_copy_flat", C.c_int64, _P, C.c_int, _P, C.c_uint64)
 _sig("rt1w_device_count", C.c_int)
@@ -304,6 +305,14 @@ class Scene:
         True = near child first in media-free subtrees.  On a committed scene, before creating contexts."""
         _ck(_lib.rt1w_scene_set_walk_order(self._h, int(near_far)))   # 0 reference, 1 near-far (result-preserving), 2 near-far everywhere
         return self
+
+    def bvh_topology(self):
+        """The trees of the opt-in SAH build as one int32 stream (rt1w_scene_get_bvh_topology); empty for the reference's build."""
+        n = int(_lib.rt1w_scene_get_bvh_topology(self._h, None, 0))
+        _ck(n)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        _ck(int(_lib.rt1w_scene_get_bvh_topology(self._h, out.ctypes.data_as(_P), n)))
+        return out[:n]
 
     def info(self):
         i = SceneInfo()

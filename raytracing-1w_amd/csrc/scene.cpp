@@ -146,7 +146,8 @@ struct Flattener {
     /* ---- opt-in SAH rebuild (the reference's build is the random-axis median split of bvh.rs:84-100) ----
      * Same leaf set, same box arithmetic (surrounding_box of the children), another tree: every split minimises
      * area(L)*|L| + area(R)*|R| over the three axes and all positions of the centroid order. */
-    struct SahItem { int id; AABB box; RtV3 c; };
+    struct SahItem { int id; AABB box; RtV3 c; int32_t orig; };
+    std::vector<int32_t>* topo = nullptr; /* where the rebuilt trees are written down (rt1w_scene_get_bvh_topology) */
     bool collect_leaves(int id, double time0, double time1, std::vector<SahItem>& items) {
         const HostHittable& h = s.hittables[id];
         if (h.kind == H_BVH) {
@@ -157,6 +158,7 @@ struct Flattener {
         it.id = id;
         if (!bounding_box(s, id, time0, time1, it.box)) return false;
         it.c = 0.5 * (it.box.minimum + it.box.maximum);
+        it.orig = (int32_t)items.size(); /* position in the reference tree's left-to-right leaf order */
         items.push_back(it);
         return true;
     }
@@ -191,7 +193,11 @@ struct Flattener {
     }
     uint32_t emit_sah(std::vector<SahItem>& items, size_t lo, size_t hi, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary,
                       uint32_t* need) {
-        if (hi - lo == 1) return emit(items[lo].id, parent_scope, scope_depth, in_boundary, need);
+        if (hi - lo == 1) {
+            if (topo) topo->push_back(items[lo].orig);
+            return emit(items[lo].id, parent_scope, scope_depth, in_boundary, need);
+        }
+        if (topo) topo->push_back(-1);
         const size_t mid = sah_split(items, lo, hi);
         AABB lb = items[lo].box, rb = items[mid].box;
         for (size_t i = lo + 1; i < mid; ++i) lb = surrounding_box(lb, items[i].box);
@@ -659,7 +665,9 @@ int rt1w_scene_commit(rt1w_scene* s) {
 /* scene graph -> pre-order node records (and the light list); run by commit and again by rt1w_scene_set_bvh_build */
 static int flatten_scene(rt1w_scene* s) {
     s->flat_nodes.clear();
+    s->bvh_topology.clear();
     Flattener f{*s, s->flat_nodes};
+    f.topo = &s->bvh_topology;
     uint32_t need = 0;
     uint32_t root = f.emit(s->world, RT_NONE, 0, false, &need);
     if (!f.ok) { s->flat_nodes.clear(); return f.err; }
@@ -790,6 +798,17 @@ int rt1w_scene_set_bvh_build(rt1w_scene* s, uint32_t mode) {
         return rc;
     }
     return rt1w_scene_set_walk_order(s, s->walk_order); /* the order annotations live in the node records */
+}
+
+int64_t rt1w_scene_get_bvh_topology(const rt1w_scene* s, int32_t* out, uint64_t capacity) {
+    if (!s) { set_error("null scene"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
+    const uint64_t n = s->bvh_topology.size();
+    if (out) {
+        if (capacity < n) { set_error("buffer too small"); return RT1W_ERR_INVALID; }
+        if (n) std::memcpy(out, s->bvh_topology.data(), n * sizeof(int32_t));
+    }
+    return (int64_t)n;
 }
 
 int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {

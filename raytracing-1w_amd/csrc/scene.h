@@ -58,6 +58,7 @@ struct rt1w_scene {
     uint32_t walk_order = 0; /* RT1W_WALK_* */
     uint32_t walk_annotated = 0; /* BVH nodes that carry an order annotation (0: the plain kernels serve) */
     uint32_t bvh_build = 0;  /* RT1W_BVH_* */
+    std::vector<int32_t> bvh_topology; /* RT1W_BVH_SAH: the rebuilt trees, see rt1w_scene_get_bvh_topology */
 };
 
 #endif

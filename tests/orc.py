@@ -34,6 +34,9 @@ for _L in (A, REF):
     _L.orc_render_checkpoints.argtypes = [_P] + [C.c_uint32] * 10 + [C.c_int, C.c_int, _P, C.c_uint32, _P, C.POINTER(C.c_uint64)]
     _L.orc_quantize.argtypes = [_P, C.c_uint64, _P]
     _L.orc_is_refstream.restype = C.c_int
+for _L in (A, REF):
+    _L.orc_scene_apply_topology.restype = C.c_int
+    _L.orc_scene_apply_topology.argtypes = [_P, _P, C.c_uint64]
 REF.orc_ref_chacha_block.argtypes = [_P, C.c_uint64, C.c_int, _P]
 REF.orc_ref_stdrng_construction.argtypes = [_P, _P]
 REF.orc_ref_words.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, _P]
@@ -114,6 +117,14 @@ class OracleScene:
                                              threads, cp, len(checkpoints), out.ctypes.data_as(_P), C.byref(seg))
         assert rc == 0
         return out, {"segments": seg.value, "paths": tw * th * checkpoints[-1]}
+
+    def apply_topology(self, topo):
+        """Rebuild every BVH of this oracle scene over its own leaves with the trees of `topo` (the product's opt-in SAH build,
+        Scene.bvh_topology()); afterwards render() runs the literal BVHNode::hit over those trees.  Returns self."""
+        t = np.ascontiguousarray(topo, dtype=np.int32)
+        rc = self.lib.orc_scene_apply_topology(self._h, t.ctypes.data_as(_P), t.size)
+        assert rc == 0, "the topology stream does not fit this scene"
+        return self
 
     def quantize(self, means):
         """The oracle's own quantiser (color.rs:56-65), not the product's."""

@@ -69,6 +69,51 @@ def test_sah_build_frames(rt, arm):
         assert abs(sa["segments"] - sb["segments"]) < 0.01 * sa["segments"]
 
 
+RTOL = 1e-12
+
+
+def _close(a, b):
+    both_nan = np.isnan(a) & np.isnan(b)
+    return bool((both_nan | (np.abs(a - b) <= RTOL * np.abs(a)) | (a == b)).all())
+
+
+@pytest.mark.parametrize("arm", sorted(ARMS))
+def test_sah_trees_against_the_literal_oracle_on_the_same_topology(rt, arm):
+    """INDEPENDENT check of the rebuilt trees (round-2 review: the SAH frames of arms 0 and 7 were only compared with the CPU
+    build of the product's own core).  The product writes its trees down (rt1w_scene_get_bvh_topology); the literal oracle rebuilds
+    ITS object graph over the same leaves with those trees -- boxes by its own surrounding_box, walk by its own recursive
+    BVHNode::hit (bvh.rs:25-50) -- and the iterative core on the product's flattened SAH scene must reproduce it like it does
+    on the reference's trees: equal segment counts, <= 1e-12 relative."""
+    W, H, spp = ARMS[arm]
+    aspect = 1.5 if arm == 0 else None
+    sah = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build(True)
+    topo = sah.bvh_topology()
+    assert (topo.size > 0 and (topo == -1).sum() >= 1) or arm == 3       # earth: one sphere under BVHChild::One, kept as built
+    oracle = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect).apply_topology(topo)
+    a, sa = oracle.render(W, H, spp)
+    b, sb = orc.flat_render(sah, W, H, spp)
+    assert sa["segments"] == sb["segments"], (arm, sa["segments"], sb["segments"])
+    assert _close(a, b), arm
+    # the reference build has no stream; a stream that does not fit is refused
+    assert rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).bvh_topology().size == 0
+    if topo.size:
+        bad = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect)
+        assert bad.lib.orc_scene_apply_topology(bad._h, topo[:-1].ctypes.data_as(orc._P), topo.size - 1) != 0
+
+
+def test_sah_trees_of_random_graphs_against_the_literal_oracle(rt):
+    """The same on 24 random graphs: nested BVHs merged into their parent's leaf set, BVHs under wrappers and inside AABoxes,
+    one-object BVHs (kept as built), media boundaries."""
+    for seed in range(24):
+        prod, oracle = random_scene_pair(3000 + seed)
+        prod.set_bvh_build(True)
+        oracle.apply_topology(prod.bvh_topology())
+        W, H, spp = 28, 20, 4
+        a, sa = oracle.render(W, H, spp)
+        b, sb = orc.flat_render(prod, W, H, spp, variant=3)
+        assert sa["segments"] == sb["segments"] and _close(a, b), seed
+
+
 def test_sah_build_on_random_graphs(rt):
     """24 random graphs (mirror boxes, nested wrappers, media, every primitive)."""
     identical, worst = 0, 0.0
@@ -116,6 +161,12 @@ def test_sah_build_on_the_gpu(rt, gpu_ctx_factory):
     the scene-specialised sweep (Cornell: another topology, another generated kernel) -- bit-identical to the CPU build of the core."""
     for arm, W, H, spp, aspect in ((0, 96, 64, 8, 1.5), (7, 64, 64, 8, None), (5, 64, 64, 16, None)):
         sc = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build(True)
+        # the independent check first: the literal oracle over the product's trees (reference walk order on both sides)
+        lit, sl = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect).apply_topology(sc.bvh_topology()).render(W, H, spp)
+        ctx0 = gpu_ctx_factory(sc)
+        g0, s0 = ctx0.render(W, H, spp, generic=True)
+        assert s0["segments"] == sl["segments"] and _close(lit, g0), arm
+        ctx0.close()
         if arm == 7:
             sc.set_walk_order(1)
         want, sw = orc.flat_render(sc, W, H, spp)
@@ -124,6 +175,7 @@ def test_sah_build_on_the_gpu(rt, gpu_ctx_factory):
             assert ctx.specialise()["active"]
         got, sg = ctx.render(W, H, spp)
         assert np.array_equal(got, want, equal_nan=True) and sg["segments"] == sw["segments"], arm
+        assert _close(lit, got), arm   # near-far on top (arm 7) must still give the literal oracle's frame
         if arm != 5:
             wf, swf = ctx.render(W, H, spp, wavefront=True)
             assert np.array_equal(wf, want, equal_nan=True) and swf["segments"] == sw["segments"], arm
