@@ -956,6 +956,10 @@ int rt1w_host_register(void* p, uint64_t bytes) {
 }
 int rt1w_host_unregister(void* p) { if (p && !hip_ok(hipHostUnregister(p), "hipHostUnregister")) return RT1W_ERR_DEVICE; return RT1W_OK; }
 
+/* for walk_lab.hip (diagnostics): the scene view the kernels get, and the device */
+const void* rt1w_internal_view(const rt1w_context* c) { return &c->view; }
+int rt1w_internal_device(const rt1w_context* c) { return c->device; }
+
 int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* out_fast, uint64_t n) {
     if (!c || !in || !out_literal || !out_fast) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
     if (n == 0) return RT1W_OK;

@@ -1,0 +1,634 @@
+/* walk_lab.hip -- TRACE-ONLY HARNESS ("walk lab") for closest-hit candidates.  gfx950 only.
+ *
+ * Why it exists (round-2 review): every experiment on the BVH walk used to cost a full render and a full test suite,
+ * and the decision on wide / restructured walks had been taken by estimate.  The lab separates the question "how fast can
+ * `world.hit(ray, 0.001, inf)` (src/main.rs:62 -> src/bvh.rs:25-50, src/aabb.rs:13-32 and the leaves' `hit`) be answered
+ * for the rays real paths produce?" from everything else:
+ *
+ *   rt1w_lab_dump_rays   runs real paths of a tile with the product's own core (rt_path_begin / rt_path_step) and
+ *                        writes down the ray each path traces at bounce 0, 1, 2, ... -- the ray population of a render;
+ *   rt1w_lab_set_rays    uploads any selection / order of them;
+ *   rt1w_lab_trace       times ONLY the closest-hit search over those rays with one of the walks below, in a persistent
+ *                        kernel whose idle lanes refill from the ray list (as the render kernels do), and returns
+ *                        (t, primitive) per ray so that candidates are compared with the product's walk BIT FOR BIT.
+ *
+ * Walks:
+ *   mode 0  W0: the product's stack walk (rt_walk_begin / rt_walk_step of rt_core.h), one stack entry per step.
+ *   mode 1  W1: pair walk in two phases (see below) -- media-free, wrapper-free scenes whose primitives sit under
+ *           BVHChild::One or under a two-object BVHChild::Two (what BVHNode::new builds, bvh.rs:63-79).
+ *
+ * The lab is a measuring instrument: it ships in the library, but no render entry point reaches it.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt1w.h"
+#include "rt_kernel_sorted.h" /* rt_core.h, LdsStack, lane_prefix */
+#include "scene.h"
+#include "walk_lab.h"
+
+extern "C" const void* rt1w_internal_view(const rt1w_context* c);
+extern "C" int rt1w_internal_device(const rt1w_context* c);
+
+namespace {
+
+bool lab_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    rt1w::set_error(std::string("walk lab: ") + what + ": " + hipGetErrorString(e));
+    return false;
+}
+
+/* ------------------------------------------------------------------------------------------------ ray dump -- */
+
+/* one thread per path of the tile (work items of one sample: 8x8 pixel blocks, like the render kernels): the ray traced at
+ * bounce b goes to out[(b * n_paths + path) * 8] = {o.xyz, d.xyz, time, 1.0}; paths that ended before bounce b leave 0.0 in
+ * slot 7.  Variant V3 (every feature, stack walk) serves every scene. */
+__global__ __launch_bounds__(RT_BLOCK, 2) void lab_dump_kernel(RtSceneView sc, RtFrame f, uint32_t n_bounces, unsigned long long n_paths,
+                                                               double* __restrict__ out) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    RtGlobalNodes ns{sc.nodes};
+    const unsigned long long item = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (item >= rt_item_count(f)) return;
+    uint32_t px, py, chunk;
+    rt_item_decode(f, item, px, py, chunk);
+    if (px >= f.tile_w || py >= f.tile_h) return;
+    const unsigned long long path = ((unsigned long long)py * f.tile_w + px) * f.spp + chunk;
+    RtPath p;
+    rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + chunk, p);
+    for (uint32_t b = 0; b < n_bounces; ++b) {
+        double* o = out + ((unsigned long long)b * n_paths + path) * 8ull;
+        const bool traces = p.alive && p.depth_left != 0u;
+        o[0] = p.ray.o.x; o[1] = p.ray.o.y; o[2] = p.ray.o.z;
+        o[3] = p.ray.d.x; o[4] = p.ray.d.y; o[5] = p.ray.d.z;
+        o[6] = p.ray.time; o[7] = traces ? 1.0 : 0.0;
+        if (!traces) { for (uint32_t k = b + 1; k < n_bounces; ++k) out[((unsigned long long)k * n_paths + path) * 8ull + 7ull] = 0.0; return; }
+        rt_path_step<RtCfgV3>(sc, ns, p, stk);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- common frame -- */
+
+struct LabRay { double o[3], d[3], time, pad; };
+struct LabHit { double t; uint32_t prim; uint32_t flags; }; /* flags: bit 0 = answered by the fallback walk */
+
+/* wave-aggregated fetch of the next ray index for the lanes that ask (one atomic per wave) */
+__device__ __forceinline__ unsigned long long lab_fetch(bool want, unsigned long long* counter) {
+    unsigned long long idx = ~0ull;
+    if (want) {
+        const unsigned long long need = __ballot(1);
+        const uint32_t cnt = (uint32_t)__popcll(need);
+        const uint32_t rank = lane_prefix(need);
+        unsigned long long base = 0;
+        if (rank == 0u) base = atomicAdd(counter, (unsigned long long)cnt);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        idx = (((unsigned long long)hi << 32) | lo) + rank;
+    }
+    return idx;
+}
+
+/* ------------------------------------------------------------------------------------------------- W0 -- */
+
+/* the product's walk, one entry per step; idle lanes refill once `refill_idle` of them wait (or nothing else can step) */
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, const LabRay* __restrict__ rays, unsigned long long n,
+                                                            LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
+                                                            unsigned long long* stats) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    RtGlobalNodes ns{sc.nodes};
+    RtWalk k;
+    RtRng rng = rt_rng_make(0u, 0u, 0u, 0u, RT_DOMAIN_RENDER);
+    unsigned long long mine = ~0ull;
+    bool walking = false, exhausted = false;
+    unsigned long long steps = 0, wave_steps = 0;
+    for (;;) {
+        const bool idle = !walking;
+        const unsigned long long idle_m = __ballot(idle && !exhausted);
+        const unsigned long long walk_m = __ballot(walking);
+        if ((uint32_t)__popcll(idle_m) >= refill_idle || walk_m == 0ull) {
+            if (idle && !exhausted) {
+                if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = 0u; out[mine] = h; mine = ~0ull; }
+            }
+            const unsigned long long idx = lab_fetch(idle && !exhausted, counter);
+            if (idle && !exhausted) {
+                if (idx < n) {
+                    const LabRay r = rays[idx];
+                    RtRay w; w.o = rt_v3(r.o[0], r.o[1], r.o[2]); w.d = rt_v3(r.d[0], r.d[1], r.d[2]); w.time = r.time;
+                    rng = rt_rng_make((uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u, RT_DOMAIN_RENDER);
+                    stk.sp = 0;
+                    rt_walk_begin(k, sc.root, w, 0.001, RT_INF, stk);
+                    mine = idx; walking = true;
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(walking) == 0ull) break;
+        if (walking) {
+            rt_walk_step<Cfg, true>(sc, ns, k, rng, stk);
+            ++steps;
+            if (rt_walk_done(k, stk)) walking = false;
+        }
+        ++wave_steps;
+    }
+    if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = 0u; out[mine] = h; }
+    if (stats) {
+        atomicAdd(&stats[0], steps);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&stats[1], wave_steps);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------- W1 -- */
+
+/* PAIR WALK IN TWO PHASES.
+ *
+ * What the reference does per ray (bvh.rs:25-50): depth first, left before right, every BVH node's box tested with the
+ * closest hit so far as t_max, every object under a passed node tested the same way.  What costs on the GPU is not that
+ * arithmetic but running it for a few lanes at a time: in a one-entry-per-step walk each wave step executes the box code,
+ * the sphere code and the moving-sphere code one after the other, each for the lanes that happen to be at that kind
+ * (25 % of the lanes active per VALU instruction on random_scene, PMC).
+ *
+ * Here a lane's walk is split into the two kinds of work, and the WAVE decides which kind it runs next:
+ *   box phase   every stepping lane visits one inner node: ONE 128-byte record holds the boxes of both children, both are
+ *               tested, the left one is entered (the right one pushed) -- no leaf arithmetic in this phase.  A child that
+ *               is a LEAF GROUP (a BVH node whose children are primitives: BVHChild::One(prim) or Two(prim, prim)) is not
+ *               entered but appended to the lane's queue of pending groups, in the order the reference reaches them;
+ *   leaf phase  every lane with a pending group handles its oldest one: the group's own box is tested with the closest hit
+ *               AS IT IS NOW, then its one or two primitives in the reference's order (left = first, bvh.rs:38-47).
+ *
+ * Exactness.  The box phase runs ahead of the leaf phase, so its box tests see a closest hit that may be STALE (not yet
+ * lowered by the pending groups).  A stale t_max can only make a box pass that the reference would have failed, never the
+ * reverse (the slab verdict is min(exit, t_max) > enter: monotone in t_max).  Every primitive's gate -- its group's own box
+ * -- is re-evaluated in the leaf phase at exactly the closest hit the reference has when it reaches that group, because
+ * groups are handled strictly in the reference's order and nothing else changes the closest hit.  The inner boxes above a
+ * group need no second look: a child's box lies inside its parent's (surrounding_box, aabb.rs:35-52), so a group box that
+ * passes at t implies every box above it passes at t, hence at the larger t_max the reference tested it with.  So the set
+ * of primitives tested, their order and every operand are the reference's: same bits.  Stack entries carry the entry
+ * distance of the pushed box (rounded DOWN to f32: culling at the pop is allowed to miss, never to over-cull).
+ * A closest hit that turns NaN (a NaN root is accepted, sphere.rs:43-48) breaks monotonicity: such a ray is answered by
+ * the product's walk from scratch (flag bit 0).
+ */
+struct LabPNode { /* inner node: both children's boxes (min.xyz, max.xyz) and what the children are */
+    double lb[6], rb[6];
+    uint32_t l, r;       /* child reference: LAB_LEAF | group index, or inner index */
+    uint32_t pad[6];
+};                       /* 128 bytes */
+struct LabPrim {
+    double c0[3], dc[3]; /* Sphere: centre, 0; MovingSphere: center0, center1 - center0 (moving_sphere.rs:23-26) */
+    double radius;
+    uint32_t id;         /* index of the primitive's RtNode (what the product's walk reports) */
+    uint32_t moving;
+};                       /* 64 bytes */
+struct LabGroup {
+    double box[6];       /* the group's own box: BVHNode.aabb of the One / Two node */
+    uint32_t n, pad[3];
+    LabPrim p[2];
+};                       /* 192 bytes */
+#define LAB_LEAF 0x80000000u
+#define LAB_NONE 0xFFFFFFFFu
+#define LAB_QCAP 4       /* pending groups per lane */
+#define LAB_W1_STACK 24
+#define LAB_W1_BLOCK 256
+
+struct LabW1Scene {
+    const LabPNode* inner;
+    const LabGroup* groups;
+    double root_box[6];
+    uint32_t root;       /* reference of the root (inner or LAB_LEAF | group) */
+    double ms_time0, ms_time1;
+};
+
+__device__ __forceinline__ void lab_slab(const double* bb, RtV3 o, RtV3 inv, double t_min, double& enter, double& exit_) {
+    /* aabb.rs:14-29 with the interval kept by max/min (rt_aabb_hit_fast's arithmetic), without folding t_max in */
+    double lo = t_min, hi = RT_INF;
+#define LAB_AX(minv, maxv, ov, iv)                       \
+    {                                                    \
+        double t0 = ((minv) - (ov)) * (iv);              \
+        double t1 = ((maxv) - (ov)) * (iv);              \
+        if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
+        lo = rt_vmax(t0, lo);                            \
+        hi = rt_vmin(t1, hi);                            \
+    }
+    LAB_AX(bb[0], bb[3], o.x, inv.x)
+    LAB_AX(bb[1], bb[4], o.y, inv.y)
+    LAB_AX(bb[2], bb[5], o.z, inv.z)
+#undef LAB_AX
+    enter = lo; exit_ = hi;
+}
+
+#define LAB_LDS_INNER 256 /* inner pair records kept in LDS by the experiment kernel (32 KB) */
+#define LAB_LDS_STACK 16
+template <bool LDS_INNER>
+__global__ __launch_bounds__(LAB_W1_BLOCK, LDS_INNER ? 2 : 3) void lab_trace_w1(LabW1Scene ps, const LabRay* __restrict__ rays, unsigned long long n,
+                                                                 LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
+                                                                 uint32_t leaf_votes, unsigned long long* stats, uint32_t n_inner) {
+    __shared__ uint32_t s_ref[(LDS_INNER ? LAB_LDS_STACK : LAB_W1_STACK) * LAB_W1_BLOCK];
+    __shared__ float s_ent[(LDS_INNER ? LAB_LDS_STACK : LAB_W1_STACK) * LAB_W1_BLOCK];
+    __shared__ uint32_t s_q[LAB_QCAP * LAB_W1_BLOCK];
+    __shared__ LabPNode s_inner[LDS_INNER ? LAB_LDS_INNER : 1];
+    if constexpr (LDS_INNER) {
+        const uint4* src = reinterpret_cast<const uint4*>(ps.inner);
+        uint4* dst = reinterpret_cast<uint4*>(s_inner);
+        for (uint32_t i = threadIdx.x; i < n_inner * 8u; i += LAB_W1_BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    uint32_t* const my_ref = s_ref + threadIdx.x;
+    float* const my_ent = s_ent + threadIdx.x;
+    uint32_t* const my_q = s_q + threadIdx.x;
+
+    RtV3 o = rt_v3(0, 0, 0), d = rt_v3(0, 0, 0), inv = rt_v3(0, 0, 0);
+    double frac = 0.0, best_t = RT_INF;
+    uint32_t best_prim = RT_NONE;
+    int sp = 0;
+    uint32_t cur = LAB_NONE, qh = 0u, qn = 0u;
+    unsigned long long mine = ~0ull;
+    bool walking = false, exhausted = false, bad = false;
+    unsigned long long n_box = 0, n_leaf = 0, w_box = 0, w_leaf = 0;
+    const double t_min = 0.001;
+
+    for (;;) {
+        /* ---- refill -------------------------------------------------------------------------------------------- */
+        {
+            const bool idle = !walking;
+            const unsigned long long idle_m = __ballot(idle && !exhausted);
+            if ((uint32_t)__popcll(idle_m) >= refill_idle || __ballot(walking) == 0ull) {
+                if (idle && !exhausted && mine != ~0ull) {
+                    LabHit h; h.t = best_t; h.prim = best_prim; h.flags = bad ? 1u : 0u; out[mine] = h; mine = ~0ull;
+                }
+                const unsigned long long idx = lab_fetch(idle && !exhausted, counter);
+                if (idle && !exhausted) {
+                    if (idx < n) {
+                        const LabRay r = rays[idx];
+                        o = rt_v3(r.o[0], r.o[1], r.o[2]); d = rt_v3(r.d[0], r.d[1], r.d[2]);
+                        inv = rt_inv3(d);
+                        frac = (r.time - ps.ms_time0) / (ps.ms_time1 - ps.ms_time0);
+                        best_t = RT_INF; best_prim = RT_NONE; bad = false;
+                        sp = 0; qh = 0u; qn = 0u; cur = LAB_NONE;
+                        mine = idx; walking = true;
+                        /* the root's own box, exactly as the reference tests it first (bvh.rs:32) */
+                        if (rt_aabb_hit_fast<false>(ps.root_box, o, inv, t_min, best_t)) {
+                            if (ps.root & LAB_LEAF) { my_q[0] = ps.root & ~LAB_LEAF; qn = 1u; }
+                            else cur = ps.root;
+                        } else walking = false;
+                        if (rt_isnan(frac)) { bad = true; walking = false; } /* no moving-sphere arithmetic on a NaN shutter fraction here */
+                    } else exhausted = true;
+                }
+            }
+        }
+        if (__ballot(walking) == 0ull) break;
+
+        /* ---- which phase ----------------------------------------------------------------------------------------- */
+        const bool can_box = walking && (cur != LAB_NONE || sp > 0) && qn + 2u <= (uint32_t)LAB_QCAP;
+        const bool can_leaf = walking && qn > 0u;
+        const uint32_t nb = (uint32_t)__popcll(__ballot(can_box)), nl = (uint32_t)__popcll(__ballot(can_leaf));
+        if (nl >= leaf_votes || nb == 0u) {
+            /* ---- leaf phase: the oldest pending group of every lane that has one ---------------------------------- */
+            if (can_leaf) {
+                const uint32_t g = my_q[(qh & (LAB_QCAP - 1u)) * LAB_W1_BLOCK];
+                qh += 1u; qn -= 1u;
+                const LabGroup& G = ps.groups[g];
+                ++n_leaf;
+                if (rt_aabb_hit_fast<false>(G.box, o, inv, t_min, best_t)) { /* the gate, at the closest hit as it is NOW */
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i < (int)G.n) {
+                            const LabPrim& P = G.p[i];
+                            RtV3 c = rt_v3(P.c0[0], P.c0[1], P.c0[2]);
+                            if (P.moving) c = c + frac * rt_v3(P.dc[0], P.dc[1], P.dc[2]); /* moving_sphere.rs:23-26 */
+                            double t;
+                            if (rt_sphere_root(c, P.radius, o, d, t_min, best_t, t)) { best_t = t; best_prim = P.id; }
+                        }
+                    }
+                    if (rt_isnan(best_t)) { bad = true; walking = false; }
+                }
+            }
+            ++w_leaf;
+        } else {
+            /* ---- box phase: one inner node per stepping lane ------------------------------------------------------ */
+            if (can_box) {
+                if (cur == LAB_NONE) { /* back to the nearest pushed right child */
+                    --sp;
+                    const uint32_t ref = my_ref[sp * LAB_W1_BLOCK];
+                    const float ent = my_ent[sp * LAB_W1_BLOCK];
+                    if ((double)ent < best_t) { /* conservative cull: ent <= the box's entry distance */
+                        if (ref & LAB_LEAF) { my_q[((qh + qn) & (LAB_QCAP - 1u)) * LAB_W1_BLOCK] = ref & ~LAB_LEAF; qn += 1u; }
+                        else cur = ref;
+                    }
+                }
+                if (cur != LAB_NONE) {
+                    const LabPNode& P = LDS_INNER ? s_inner[cur] : ps.inner[cur];
+                    ++n_box;
+                    double el, xl, er, xr;
+                    lab_slab(P.lb, o, inv, t_min, el, xl);
+                    lab_slab(P.rb, o, inv, t_min, er, xr);
+                    const bool pl = rt_vmin(xl, best_t) > el, pr = rt_vmin(xr, best_t) > er;
+                    const uint32_t l = P.l, r = P.r;
+                    uint32_t next = LAB_NONE;
+                    bool left_entered = false;
+                    if (pl) {
+                        if (l & LAB_LEAF) { my_q[((qh + qn) & (LAB_QCAP - 1u)) * LAB_W1_BLOCK] = l & ~LAB_LEAF; qn += 1u; }
+                        else { next = l; left_entered = true; }
+                    }
+                    if (pr) {
+                        if (left_entered) { /* after the left subtree: bvh.rs:38-47 */
+                            my_ref[sp * LAB_W1_BLOCK] = r;
+                            my_ent[sp * LAB_W1_BLOCK] = __double2float_rd(er);
+                            ++sp;
+                        } else if (r & LAB_LEAF) { my_q[((qh + qn) & (LAB_QCAP - 1u)) * LAB_W1_BLOCK] = r & ~LAB_LEAF; qn += 1u; }
+                        else next = r;
+                    }
+                    cur = next;
+                }
+            }
+            ++w_box;
+        }
+        if (walking && cur == LAB_NONE && sp == 0 && qn == 0u) walking = false;
+    }
+    if (mine != ~0ull) { LabHit h; h.t = best_t; h.prim = best_prim; h.flags = bad ? 1u : 0u; out[mine] = h; }
+    if (stats) {
+        atomicAdd(&stats[0], n_box);
+        atomicAdd(&stats[2], n_leaf);
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&stats[1], w_box); atomicAdd(&stats[3], w_leaf); }
+    }
+}
+
+/* rays W1 could not answer (flag bit 0): the product's walk from scratch, one thread per ray */
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, 2) void lab_fallback(RtSceneView sc, const LabRay* __restrict__ rays, unsigned long long n, LabHit* __restrict__ out) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    const unsigned long long i = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n || (out[i].flags & 1u) == 0u) return;
+    RtGlobalNodes ns{sc.nodes};
+    const LabRay r = rays[i];
+    RtRay w; w.o = rt_v3(r.o[0], r.o[1], r.o[2]); w.d = rt_v3(r.d[0], r.d[1], r.d[2]); w.time = r.time;
+    RtRng rng = rt_rng_make((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u, RT_DOMAIN_RENDER);
+    double t; uint32_t prim, scope;
+    rt_traverse_stack<Cfg, true>(sc, ns, sc.root, w, 0.001, RT_INF, rng, stk, t, prim, scope);
+    LabHit h; h.t = t; h.prim = prim; h.flags = 1u;
+    out[i] = h;
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------------------------------------------ host -- */
+
+struct rt1w_lab {
+    rt1w_context* ctx = nullptr;
+    RtSceneView view{};
+    int device = 0, cus = 0;
+    int variant = 3;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LabRay* d_rays = nullptr; unsigned long long n_rays = 0;
+    LabHit* d_hits = nullptr;
+    unsigned long long* d_counter = nullptr; /* [0] ray counter, [1..8] stats */
+    /* W1 */
+    bool w1_ok = false; std::string w1_why;
+    LabPNode* d_inner = nullptr; LabGroup* d_groups = nullptr;
+    LabW1Scene w1{};
+    uint32_t n_inner = 0, n_groups = 0, stack_need = 0;
+};
+
+namespace {
+
+/* flat pre-order nodes -> inner pair records + leaf groups; false (with a reason) if the scene is outside W1's scope */
+struct W1Builder {
+    const std::vector<RtNode>& N;
+    std::vector<LabPNode>& inner;
+    std::vector<LabGroup>& groups;
+    bool ok = true;
+    std::string why;
+    uint32_t kind(uint32_t i) const { return N[i].kind & RT_KIND_MASK; }
+    bool is_prim(uint32_t i) const { return kind(i) == RT_SPHERE || kind(i) == RT_MSPHERE; }
+    bool is_group(uint32_t i) const {
+        if (kind(i) == RT_BVH1) return is_prim(N[i].a);
+        if (kind(i) == RT_BVH2) return is_prim(N[i].a) && is_prim(N[i].b);
+        return false;
+    }
+    LabPrim prim_of(uint32_t i) const {
+        LabPrim p; memset(&p, 0, sizeof p);
+        const RtNode& n = N[i];
+        p.id = i;
+        if (kind(i) == RT_MSPHERE) {
+            p.moving = 1u;
+            for (int a = 0; a < 3; ++a) { p.c0[a] = n.d[a]; p.dc[a] = n.d[3 + a] - n.d[a]; } /* center1 - center0: the reference's own subtraction */
+            p.radius = n.e[2];
+        } else {
+            for (int a = 0; a < 3; ++a) { p.c0[a] = n.d[a]; p.dc[a] = 0.0; }
+            p.radius = n.d[3];
+        }
+        return p;
+    }
+    uint32_t go(uint32_t i) {
+        if (!ok) return LAB_NONE;
+        if (is_group(i)) {
+            LabGroup g; memset(&g, 0, sizeof g);
+            for (int a = 0; a < 6; ++a) g.box[a] = N[i].d[a];
+            g.n = kind(i) == RT_BVH2 ? 2u : 1u;
+            g.p[0] = prim_of(N[i].a);
+            if (g.n == 2u) g.p[1] = prim_of(N[i].b);
+            groups.push_back(g);
+            return LAB_LEAF | (uint32_t)(groups.size() - 1);
+        }
+        if (kind(i) == RT_BVH1) { ok = false; why = "BVHChild::One over a BVH node"; return LAB_NONE; } /* not built by BVHNode::new, legal through the ABI */
+        if (kind(i) != RT_BVH2 || is_prim(N[i].a) || is_prim(N[i].b)) { ok = false; why = "a BVHChild::Two with one primitive and one subtree"; return LAB_NONE; }
+        const uint32_t me = (uint32_t)inner.size();
+        inner.push_back(LabPNode());
+        memset(&inner[me], 0, sizeof(LabPNode));
+        const uint32_t a = N[i].a, b = N[i].b;
+        for (int q = 0; q < 6; ++q) { inner[me].lb[q] = N[a].d[q]; inner[me].rb[q] = N[b].d[q]; }
+        const uint32_t l = go(a);
+        const uint32_t r = go(b);
+        inner[me].l = l; inner[me].r = r;
+        return me;
+    }
+};
+bool build_w1(const std::vector<RtNode>& N, uint32_t root, std::vector<LabPNode>& inner, std::vector<LabGroup>& groups, LabW1Scene& sc,
+              std::string& why) {
+    W1Builder b{N, inner, groups};
+    bool seen_ms = false;
+    double t0 = 0.0, t1 = 1.0;
+    for (uint32_t i = 0; i < N.size(); ++i) {
+        const uint32_t k = b.kind(i);
+        if (k == RT_BVH2 || k == RT_BVH1) continue;
+        if (!b.is_prim(i)) { why = "a node that is neither a BVH node nor a sphere (W1 covers sphere scenes only so far)"; return false; }
+        if (N[i].kind & RT_LEAF_FLIPPED) { why = "FlipFace"; return false; }
+        if (k == RT_MSPHERE) {
+            if (!seen_ms) { t0 = N[i].e[0]; t1 = N[i].e[1]; seen_ms = true; }
+            else if (memcmp(&t0, &N[i].e[0], 8) != 0 || memcmp(&t1, &N[i].e[1], 8) != 0) { why = "moving spheres with different shutter intervals"; return false; }
+        }
+    }
+    sc.ms_time0 = t0; sc.ms_time1 = t1;
+    const uint32_t k0 = b.kind(root);
+    if (k0 != RT_BVH2 && k0 != RT_BVH1) { why = "the root is not a BVH node"; return false; }
+    for (int a = 0; a < 6; ++a) sc.root_box[a] = N[root].d[a];
+    sc.root = b.go(root);
+    why = b.why;
+    return b.ok;
+}
+
+template <class T>
+bool lab_upload(T** dst, const std::vector<T>& v) {
+    *dst = nullptr;
+    const size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
+    if (!lab_ok(hipMalloc((void**)dst, bytes), "hipMalloc")) return false;
+    if (v.size() && !lab_ok(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy")) return false;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt1w_lab_create(rt1w_context* c, const rt1w_scene* s, rt1w_lab** out) {
+    if (!c || !s || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { rt1w::set_error("scene not committed"); return RT1W_ERR_STATE; }
+    rt1w_lab* l = new (std::nothrow) rt1w_lab();
+    if (!l) { rt1w::set_error("out of memory"); return RT1W_ERR_NOMEM; }
+    l->ctx = c;
+    memcpy(&l->view, rt1w_internal_view(c), sizeof(RtSceneView));
+    l->device = rt1w_internal_device(c);
+    hipDeviceProp_t prop;
+    if (!lab_ok(hipSetDevice(l->device), "hipSetDevice") || !lab_ok(hipGetDeviceProperties(&prop, l->device), "hipGetDeviceProperties") ||
+        !lab_ok(hipStreamCreate(&l->stream), "hipStreamCreate") || !lab_ok(hipEventCreate(&l->ev0), "hipEventCreate") ||
+        !lab_ok(hipEventCreate(&l->ev1), "hipEventCreate") || !lab_ok(hipMalloc((void**)&l->d_counter, 16 * sizeof(unsigned long long)), "hipMalloc")) {
+        rt1w_lab_destroy(l); return RT1W_ERR_DEVICE;
+    }
+    l->cus = prop.multiProcessorCount;
+    l->variant = (!s->has_media && s->scope_depth == 0u) ? 5 : (s->has_media ? 3 : 2);
+    std::vector<LabPNode> inner; std::vector<LabGroup> groups;
+    l->w1_ok = build_w1(s->flat_nodes, s->flat_root, inner, groups, l->w1, l->w1_why) && s->stack_need <= (uint32_t)LAB_W1_STACK;
+    if (l->w1_ok) {
+        if (!lab_upload(&l->d_inner, inner) || !lab_upload(&l->d_groups, groups)) { rt1w_lab_destroy(l); return RT1W_ERR_DEVICE; }
+        l->w1.inner = l->d_inner; l->w1.groups = l->d_groups;
+        l->n_inner = (uint32_t)inner.size(); l->n_groups = (uint32_t)groups.size(); l->stack_need = s->stack_need;
+    }
+    *out = l;
+    return RT1W_OK;
+}
+
+void rt1w_lab_destroy(rt1w_lab* l) {
+    if (!l) return;
+    if (l->d_rays) (void)hipFree(l->d_rays);
+    if (l->d_hits) (void)hipFree(l->d_hits);
+    if (l->d_counter) (void)hipFree(l->d_counter);
+    if (l->d_inner) (void)hipFree(l->d_inner);
+    if (l->d_groups) (void)hipFree(l->d_groups);
+    if (l->ev0) (void)hipEventDestroy(l->ev0);
+    if (l->ev1) (void)hipEventDestroy(l->ev1);
+    if (l->stream) (void)hipStreamDestroy(l->stream);
+    delete l;
+}
+
+int rt1w_lab_info(const rt1w_lab* l, uint32_t out[4]) {
+    if (!l || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    out[0] = l->w1_ok ? 1u : 0u; out[1] = l->n_inner; out[2] = l->n_groups; out[3] = (uint32_t)l->variant;
+    if (!l->w1_ok) rt1w::set_error("W1 not available for this scene: " + l->w1_why);
+    return RT1W_OK;
+}
+
+int rt1w_lab_dump_rays(rt1w_lab* l, const rt1w_render_params* p, uint32_t n_bounces, double* out_host) {
+    if (!l || !p || !out_host || n_bounces == 0u) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (p->tile_w == 0 || p->tile_h == 0 || p->x0 + p->tile_w > p->width || p->y0 + p->tile_h > p->height || p->spp == 0) { rt1w::set_error("bad tile"); return RT1W_ERR_INVALID; }
+    RtFrame f; memset(&f, 0, sizeof f);
+    f.width = p->width; f.height = p->height; f.x0 = p->x0; f.y0 = p->y0; f.tile_w = p->tile_w; f.tile_h = p->tile_h;
+    f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth ? p->max_depth : 50u; f.global_seed = p->global_seed;
+    f.chunk = 1u; f.n_chunks = p->spp; f.strip_rows = 0u; f.strip_period = 0u;
+    const unsigned long long n_paths = (unsigned long long)f.tile_w * f.tile_h * f.spp;
+    const size_t bytes = (size_t)n_bounces * n_paths * 8u * sizeof(double);
+    double* d_out = nullptr;
+    if (!lab_ok(hipSetDevice(l->device), "hipSetDevice") || !lab_ok(hipMalloc((void**)&d_out, bytes), "hipMalloc(rays)")) return RT1W_ERR_NOMEM;
+    (void)hipMemsetAsync(d_out, 0, bytes, l->stream);
+    const unsigned long long items = rt_item_count(f);
+    const unsigned grid = (unsigned)((items + RT_BLOCK - 1) / RT_BLOCK);
+    hipLaunchKernelGGL(lab_dump_kernel, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, f, n_bounces, n_paths, d_out);
+    bool ok = lab_ok(hipGetLastError(), "launch(dump)") && lab_ok(hipStreamSynchronize(l->stream), "dump kernel") &&
+              lab_ok(hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost), "hipMemcpy(rays)");
+    (void)hipFree(d_out);
+    return ok ? RT1W_OK : RT1W_ERR_DEVICE;
+}
+
+int rt1w_lab_set_rays(rt1w_lab* l, const double* rays, uint64_t n) {
+    if (!l || !rays || n == 0) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    if (l->d_rays) { (void)hipFree(l->d_rays); l->d_rays = nullptr; }
+    if (l->d_hits) { (void)hipFree(l->d_hits); l->d_hits = nullptr; }
+    if (!lab_ok(hipMalloc((void**)&l->d_rays, n * sizeof(LabRay)), "hipMalloc(rays)") || !lab_ok(hipMalloc((void**)&l->d_hits, n * sizeof(LabHit)), "hipMalloc(hits)") ||
+        !lab_ok(hipMemcpy(l->d_rays, rays, n * sizeof(LabRay), hipMemcpyHostToDevice), "hipMemcpy(rays)")) return RT1W_ERR_DEVICE;
+    l->n_rays = n;
+    return RT1W_OK;
+}
+
+/* params: [0] refill_idle (lanes), [1] leaf_votes (W1), [2] blocks per CU (0: the occupancy query's) */
+int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats, double* out_t, uint32_t* out_prim, uint32_t* out_flags,
+                   double* ms_best, uint64_t stats_out[8]) {
+    if (!l || !l->d_rays) { rt1w::set_error("no rays set"); return RT1W_ERR_STATE; }
+    if (mode == 1 && !l->w1_ok) { rt1w::set_error("W1 not available for this scene: " + l->w1_why); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 2 && (!l->w1_ok || l->n_inner > LAB_LDS_INNER || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with LDS-resident inner records: scene too big or W1 unavailable"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode < 0 || mode > 2) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    const uint32_t refill = params && params[0] ? params[0] : 16u;
+    const uint32_t votes = params && params[1] ? params[1] : 24u;
+    int per_cu = 0;
+    const void* fn = nullptr;
+    if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
+    else fn = mode == 1 ? (const void*)lab_trace_w1<false> : (const void*)lab_trace_w1<true>;
+    if (!lab_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_BLOCK, 0), "occupancy")) return RT1W_ERR_DEVICE;
+    if (per_cu < 1) per_cu = 1;
+    if (params && params[2]) per_cu = (int)params[2] < per_cu ? (int)params[2] : per_cu;
+    const int grid = l->cus * per_cu;
+    double best = 1e30;
+    for (int rep = 0; rep < (repeats > 0 ? repeats : 1); ++rep) {
+        (void)hipMemsetAsync(l->d_counter, 0, 16 * sizeof(unsigned long long), l->stream);
+        (void)hipEventRecord(l->ev0, l->stream);
+        if (mode == 0) {
+            if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else hipLaunchKernelGGL(lab_trace_w0<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+        } else {
+            if (mode == 1) hipLaunchKernelGGL(lab_trace_w1<false>, dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
+            else hipLaunchKernelGGL(lab_trace_w1<true>, dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
+        }
+        (void)hipEventRecord(l->ev1, l->stream);
+        if (!lab_ok(hipGetLastError(), "launch(trace)") || !lab_ok(hipEventSynchronize(l->ev1), "trace kernel")) return RT1W_ERR_DEVICE;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, l->ev0, l->ev1);
+        if (ms < best) best = ms;
+    }
+    if (mode >= 1) { /* rays the pair walk handed back: the product's walk answers them (not timed: a handful per million) */
+        const unsigned g2 = (unsigned)((l->n_rays + RT_BLOCK - 1) / RT_BLOCK);
+        if (l->variant == 5) hipLaunchKernelGGL(lab_fallback<RtCfgV5>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);
+        else hipLaunchKernelGGL(lab_fallback<RtCfgV2>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);
+        if (!lab_ok(hipStreamSynchronize(l->stream), "fallback kernel")) return RT1W_ERR_DEVICE;
+    }
+    if (ms_best) *ms_best = best;
+    if (stats_out) {
+        unsigned long long h[16];
+        (void)hipMemcpy(l->d_counter + 8, &per_cu, sizeof(int), hipMemcpyHostToDevice); /* stats[7] = workgroups per CU of the launch */
+        if (!lab_ok(hipMemcpy(h, l->d_counter, sizeof h, hipMemcpyDeviceToHost), "hipMemcpy(stats)")) return RT1W_ERR_DEVICE;
+        for (int i = 0; i < 8; ++i) stats_out[i] = h[1 + i];
+    }
+    if (out_t || out_prim || out_flags) {
+        std::vector<LabHit> h(l->n_rays);
+        if (!lab_ok(hipMemcpy(h.data(), l->d_hits, l->n_rays * sizeof(LabHit), hipMemcpyDeviceToHost), "hipMemcpy(hits)")) return RT1W_ERR_DEVICE;
+        for (unsigned long long i = 0; i < l->n_rays; ++i) {
+            if (out_t) out_t[i] = h[i].t;
+            if (out_prim) out_prim[i] = h[i].prim;
+            if (out_flags) out_flags[i] = h[i].flags;
+        }
+    }
+    return RT1W_OK;
+}
+
+} // extern "C"
