@@ -543,12 +543,9 @@ RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_
 #define RT_MEDIUM_DEFER 0 /* 0: media run where they are met; 1, 2: parked and run wave-wide (rt_traverse_stack): MEASURED slower,
                             final_scene 118 -> 106 / 114 Mpaths/s at 16 spp, bit-identical (profiles/r02_medium_defer.txt) */
 #endif
-/* one stack entry */
+/* what a popped node entry `e` does once its record `nd` is there */
 template <class Cfg, bool MEDIA, class Stack, class NS>
-RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
-    uint32_t e = stk.pop();
-    if (Cfg::scope_depth > 0 && (e & RT_POP_FLAG)) { rt_walk_exit(sc, k, e); return; }
-    const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
+RT_HD void rt_walk_visit(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk, uint32_t e, const RtNodeHot& nd) {
     const uint32_t km = nd.kind & RT_KIND_MASK;
     RT_STAT_VISIT(km);
     /* the kinds are numbered so that each class is a range: the most frequent one costs one compare */
@@ -556,6 +553,14 @@ RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& r
     else if (km <= RT_YZ) rt_walk_leaf<Cfg>(sc, k, e, nd);
     else if (Cfg::scope_depth > 0 && km <= RT_FLIP) rt_walk_wrap(k, e, nd, stk); /* scope_depth 0: the scene has no wrapper node */
     else if (Cfg::media) rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
+}
+/* one stack entry */
+template <class Cfg, bool MEDIA, class Stack, class NS>
+RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& rng, Stack& stk) {
+    uint32_t e = stk.pop();
+    if (Cfg::scope_depth > 0 && (e & RT_POP_FLAG)) { rt_walk_exit(sc, k, e); return; }
+    const RtNodeHot nd = ns.hot(e); /* the hot 64 bytes, fetched in one go */
+    rt_walk_visit<Cfg, MEDIA>(sc, ns, k, rng, stk, e, nd);
 }
 
 template <class Cfg, bool MEDIA, class Stack, class NS>

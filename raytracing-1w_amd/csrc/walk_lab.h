@@ -20,6 +20,9 @@ int rt1w_lab_info(const rt1w_lab* l, uint32_t out[4]);
 /* rays traced at bounces 0 .. n_bounces-1 by the paths of the tile (spp samples per pixel): out[b][path][8] =
  * {origin, direction, time, valid}; path = (row * tile_w + column) * spp + sample */
 int rt1w_lab_dump_rays(rt1w_lab* l, const rt1w_render_params* p, uint32_t n_bounces, double* out_host);
+/* L1 gather probe: records (64 B of the node array at pseudo-random indices) per launch and the kernel ms of
+ * {own record, quad-shared} x {independent, dependent} index streams */
+int rt1w_lab_gather_probe(rt1w_lab* l, uint32_t iters, uint32_t blocks_per_cu, double out_ms[4], uint64_t* records_per_launch);
 /* rays[n][8] (slot 7 ignored) */
 int rt1w_lab_set_rays(rt1w_lab* l, const double* rays, uint64_t n);
 /* closest hit (t_min 0.001, t_max inf: main.rs:62) of every ray with walk `mode`; kernel time = best of `repeats` */

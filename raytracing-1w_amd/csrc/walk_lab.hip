@@ -14,6 +14,7 @@
  *
  * Walks:
  *   mode 0  W0: the product's stack walk (rt_walk_begin / rt_walk_step of rt_core.h), one stack entry per step.
+ *   mode 3  W0q: W0 with the node records fetched by quads (four lanes share each 64-byte access) and transposed with DPP.
  *   mode 1  W1: pair walk in two phases (see below) -- media-free, wrapper-free scenes whose primitives sit under
  *           BVHChild::One or under a two-object BVHChild::Two (what BVHNode::new builds, bvh.rs:63-79).
  *
@@ -21,6 +22,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -146,6 +148,128 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, cons
     }
 }
 
+/* ------------------------------------------------------------------------------------------------ W0q -- */
+
+/* QUAD-TRANSPOSED RECORD FETCH.  PMC of W0 (profiles/r03_lab_*): the L1 (TCP) is busy in 97 % of the cycles at 0.71 accesses per
+ * cycle while the VALU is busy in under half of them -- the walk is bound by the NUMBER OF L1 ACCESSES, and a lane that fetches
+ * its own 64-byte record with four 16-byte loads makes four of them, each to a line no neighbour shares.  The same bytes cost
+ * a quarter of the accesses when the four lanes of a quad fetch them together: load k of the step has every lane of the quad
+ * read ITS 16-byte quarter of quad-lane k's record (64 contiguous bytes per quad = one access), and a 4x4 transpose inside the
+ * quad (two DPP butterfly stages) hands every lane the four quarters of its own record.  Which lane runs which ray, and what it
+ * computes, is unchanged.  All 64 lanes must execute the fetch (DPP reads need their quad partners): it sits outside the
+ * per-lane control flow, lanes without an entry fetch node 0. */
+template <int CTRL>
+__device__ __forceinline__ uint32_t lab_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ uint4 lab_dpp4(uint4 v) { return make_uint4(lab_dpp<CTRL>(v.x), lab_dpp<CTRL>(v.y), lab_dpp<CTRL>(v.z), lab_dpp<CTRL>(v.w)); }
+__device__ __forceinline__ uint4 lab_sel4(bool c, uint4 a, uint4 b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+__device__ __forceinline__ RtNodeHot lab_quad_fetch(const RtNode* nodes, uint32_t e) {
+    const uint32_t j = threadIdx.x & 3u;
+    const char* base = reinterpret_cast<const char*>(nodes) + 16u * j;
+    const uint32_t e0 = lab_dpp<0x00>(e), e1 = lab_dpp<0x55>(e), e2 = lab_dpp<0xAA>(e), e3 = lab_dpp<0xFF>(e);
+    const uint4 v0 = *reinterpret_cast<const uint4*>(base + (size_t)e0 * sizeof(RtNode));
+    const uint4 v1 = *reinterpret_cast<const uint4*>(base + (size_t)e1 * sizeof(RtNode));
+    const uint4 v2 = *reinterpret_cast<const uint4*>(base + (size_t)e2 * sizeof(RtNode));
+    const uint4 v3 = *reinterpret_cast<const uint4*>(base + (size_t)e3 * sizeof(RtNode));
+    /* lane j holds v[k] = quarter j of record k; it wants r[m] = quarter m of record j = v[j] of lane m: a 4x4 transpose */
+    const bool even = (j & 1u) == 0u, lo = (j & 2u) == 0u;
+    const uint4 a0 = lab_sel4(even, v0, lab_dpp4<0xB1>(v1)), a1 = lab_sel4(even, lab_dpp4<0xB1>(v0), v1);
+    const uint4 a2 = lab_sel4(even, v2, lab_dpp4<0xB1>(v3)), a3 = lab_sel4(even, lab_dpp4<0xB1>(v2), v3);
+    const uint4 r0 = lab_sel4(lo, a0, lab_dpp4<0x4E>(a2)), r2 = lab_sel4(lo, lab_dpp4<0x4E>(a0), a2);
+    const uint4 r1 = lab_sel4(lo, a1, lab_dpp4<0x4E>(a3)), r3 = lab_sel4(lo, lab_dpp4<0x4E>(a1), a3);
+    union { uint4 q[4]; RtNodeHot h; } u;
+    u.q[0] = r0; u.q[1] = r1; u.q[2] = r2; u.q[3] = r3;
+    return u.h;
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0q(RtSceneView sc, const LabRay* __restrict__ rays, unsigned long long n,
+                                                             LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
+                                                             unsigned long long* stats) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    RtGlobalNodes ns{sc.nodes};
+    RtWalk k;
+    RtRng rng = rt_rng_make(0u, 0u, 0u, 0u, RT_DOMAIN_RENDER);
+    unsigned long long mine = ~0ull;
+    bool walking = false, exhausted = false;
+    unsigned long long steps = 0, wave_steps = 0;
+    for (;;) {
+        const bool idle = !walking;
+        const unsigned long long idle_m = __ballot(idle && !exhausted);
+        const unsigned long long walk_m = __ballot(walking);
+        if ((uint32_t)__popcll(idle_m) >= refill_idle || walk_m == 0ull) {
+            if (idle && !exhausted) {
+                if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = 0u; out[mine] = h; mine = ~0ull; }
+            }
+            const unsigned long long idx = lab_fetch(idle && !exhausted, counter);
+            if (idle && !exhausted) {
+                if (idx < n) {
+                    const LabRay r = rays[idx];
+                    RtRay w; w.o = rt_v3(r.o[0], r.o[1], r.o[2]); w.d = rt_v3(r.d[0], r.d[1], r.d[2]); w.time = r.time;
+                    rng = rt_rng_make((uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u, RT_DOMAIN_RENDER);
+                    stk.sp = 0;
+                    rt_walk_begin(k, sc.root, w, 0.001, RT_INF, stk);
+                    mine = idx; walking = true;
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(walking) == 0ull) break;
+        /* pop (per lane), fetch (all lanes together), visit (per lane) */
+        uint32_t e = 0u;
+        bool node = false;
+        if (walking) {
+            e = stk.pop();
+            if (Cfg::scope_depth > 0 && (e & RT_POP_FLAG)) rt_walk_exit(sc, k, e);
+            else node = true;
+        }
+        const RtNodeHot nd = lab_quad_fetch(sc.nodes, node ? e : 0u);
+        if (node) rt_walk_visit<Cfg, true>(sc, ns, k, rng, stk, e, nd);
+        if (walking) { ++steps; if (rt_walk_done(k, stk)) walking = false; }
+        ++wave_steps;
+    }
+    if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = 0u; out[mine] = h; }
+    if (stats) {
+        atomicAdd(&stats[0], steps);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&stats[1], wave_steps);
+    }
+}
+
+/* --------------------------------------------------------------------------------------- gather probe -- */
+
+/* What can the L1 deliver for the walk's access pattern?  Every lane reads `iters` 64-byte records of the node array at pseudo-random
+ * indices (an LCG per lane; DEP: the next index also depends on the bytes just read, as a walk's does).  QUAD 0: four 16-byte loads
+ * per lane to its own record (the walk's fetch); QUAD 1: the quad-shared form (four loads, each 64 contiguous bytes per quad, no
+ * transpose: the probe only sums the bytes).  Result: records per second, to set against visits per second of the walks. */
+template <int QUAD, int DEP>
+__global__ __launch_bounds__(256) void lab_gather_kernel(const RtNode* __restrict__ nodes, uint32_t n_nodes, uint32_t iters, unsigned long long* sink) {
+    uint32_t state = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t acc = 0u;
+    const uint32_t j = threadIdx.x & 3u;
+    for (uint32_t it = 0; it < iters; ++it) {
+        state = state * 1664525u + 1013904223u;
+        const uint32_t e = (uint32_t)(((unsigned long long)(state >> 8) * n_nodes) >> 24);
+        uint4 v0, v1, v2, v3;
+        if (QUAD) {
+            const char* base = reinterpret_cast<const char*>(nodes) + 16u * j;
+            const uint32_t e0 = lab_dpp<0x00>(e), e1 = lab_dpp<0x55>(e), e2 = lab_dpp<0xAA>(e), e3 = lab_dpp<0xFF>(e);
+            v0 = *reinterpret_cast<const uint4*>(base + (size_t)e0 * sizeof(RtNode));
+            v1 = *reinterpret_cast<const uint4*>(base + (size_t)e1 * sizeof(RtNode));
+            v2 = *reinterpret_cast<const uint4*>(base + (size_t)e2 * sizeof(RtNode));
+            v3 = *reinterpret_cast<const uint4*>(base + (size_t)e3 * sizeof(RtNode));
+        } else {
+            const uint4* p = reinterpret_cast<const uint4*>(nodes + e);
+            v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3];
+        }
+        const uint32_t x = v0.x ^ v0.w ^ v1.y ^ v1.z ^ v2.x ^ v2.w ^ v3.y ^ v3.z;
+        acc ^= x;
+        if (DEP) state ^= x & 0xFFu;
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
 /* ------------------------------------------------------------------------------------------------- W1 -- */
 
 /* PAIR WALK IN TWO PHASES.
@@ -192,6 +316,12 @@ struct LabGroup {
     uint32_t n, pad[3];
     LabPrim p[2];
 };                       /* 192 bytes */
+struct LabPNode32 { /* the same, boxes stored in f32 rounded OUTWARD: inner boxes only steer the walk (conservative culling), so they need
+                      not be the reference's bits -- the arithmetic on them stays f64 and monotone, hence never culls what the exact test keeps */
+    float lb[6], rb[6];
+    uint32_t l, r;
+    uint32_t pad[2];
+};                       /* 64 bytes: four 16-byte loads instead of eight */
 #define LAB_LEAF 0x80000000u
 #define LAB_NONE 0xFFFFFFFFu
 #define LAB_QCAP 4       /* pending groups per lane */
@@ -200,6 +330,7 @@ struct LabGroup {
 
 struct LabW1Scene {
     const LabPNode* inner;
+    const LabPNode32* inner32;
     const LabGroup* groups;
     double root_box[6];
     uint32_t root;       /* reference of the root (inner or LAB_LEAF | group) */
@@ -226,18 +357,19 @@ __device__ __forceinline__ void lab_slab(const double* bb, RtV3 o, RtV3 inv, dou
 
 #define LAB_LDS_INNER 256 /* inner pair records kept in LDS by the experiment kernel (32 KB) */
 #define LAB_LDS_STACK 16
-template <bool LDS_INNER>
-__global__ __launch_bounds__(LAB_W1_BLOCK, LDS_INNER ? 2 : 3) void lab_trace_w1(LabW1Scene ps, const LabRay* __restrict__ rays, unsigned long long n,
+template <bool LDS_INNER, bool F32 = false>
+__global__ __launch_bounds__(LAB_W1_BLOCK, LDS_INNER ? (F32 ? 3 : 2) : (F32 ? 4 : 3)) void lab_trace_w1(LabW1Scene ps, const LabRay* __restrict__ rays, unsigned long long n,
                                                                  LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
                                                                  uint32_t leaf_votes, unsigned long long* stats, uint32_t n_inner) {
-    __shared__ uint32_t s_ref[(LDS_INNER ? LAB_LDS_STACK : LAB_W1_STACK) * LAB_W1_BLOCK];
-    __shared__ float s_ent[(LDS_INNER ? LAB_LDS_STACK : LAB_W1_STACK) * LAB_W1_BLOCK];
+    __shared__ uint32_t s_ref[((LDS_INNER || F32) ? LAB_LDS_STACK : LAB_W1_STACK) * LAB_W1_BLOCK];
+    __shared__ float s_ent[((LDS_INNER || F32) ? LAB_LDS_STACK : LAB_W1_STACK) * LAB_W1_BLOCK];
     __shared__ uint32_t s_q[LAB_QCAP * LAB_W1_BLOCK];
-    __shared__ LabPNode s_inner[LDS_INNER ? LAB_LDS_INNER : 1];
+    __shared__ LabPNode s_inner[(LDS_INNER && !F32) ? LAB_LDS_INNER : 1];
+    __shared__ LabPNode32 s_inner32[(LDS_INNER && F32) ? LAB_LDS_INNER : 1];
     if constexpr (LDS_INNER) {
-        const uint4* src = reinterpret_cast<const uint4*>(ps.inner);
-        uint4* dst = reinterpret_cast<uint4*>(s_inner);
-        for (uint32_t i = threadIdx.x; i < n_inner * 8u; i += LAB_W1_BLOCK) dst[i] = src[i];
+        const uint4* src = F32 ? reinterpret_cast<const uint4*>(ps.inner32) : reinterpret_cast<const uint4*>(ps.inner);
+        uint4* dst = F32 ? reinterpret_cast<uint4*>(s_inner32) : reinterpret_cast<uint4*>(s_inner);
+        for (uint32_t i = threadIdx.x; i < n_inner * (F32 ? 4u : 8u); i += LAB_W1_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
     uint32_t* const my_ref = s_ref + threadIdx.x;
@@ -324,13 +456,24 @@ __global__ __launch_bounds__(LAB_W1_BLOCK, LDS_INNER ? 2 : 3) void lab_trace_w1(
                     }
                 }
                 if (cur != LAB_NONE) {
-                    const LabPNode& P = LDS_INNER ? s_inner[cur] : ps.inner[cur];
                     ++n_box;
                     double el, xl, er, xr;
-                    lab_slab(P.lb, o, inv, t_min, el, xl);
-                    lab_slab(P.rb, o, inv, t_min, er, xr);
+                    uint32_t l, r;
+                    if constexpr (F32) {
+                        const LabPNode32 P = LDS_INNER ? s_inner32[cur] : ps.inner32[cur];
+                        double lb[6], rb[6];
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) { lb[a] = (double)P.lb[a]; rb[a] = (double)P.rb[a]; }
+                        lab_slab(lb, o, inv, t_min, el, xl);
+                        lab_slab(rb, o, inv, t_min, er, xr);
+                        l = P.l; r = P.r;
+                    } else {
+                        const LabPNode& P = LDS_INNER ? s_inner[cur] : ps.inner[cur];
+                        lab_slab(P.lb, o, inv, t_min, el, xl);
+                        lab_slab(P.rb, o, inv, t_min, er, xr);
+                        l = P.l; r = P.r;
+                    }
                     const bool pl = rt_vmin(xl, best_t) > el, pr = rt_vmin(xr, best_t) > er;
-                    const uint32_t l = P.l, r = P.r;
                     uint32_t next = LAB_NONE;
                     bool left_entered = false;
                     if (pl) {
@@ -395,7 +538,7 @@ struct rt1w_lab {
     unsigned long long* d_counter = nullptr; /* [0] ray counter, [1..8] stats */
     /* W1 */
     bool w1_ok = false; std::string w1_why;
-    LabPNode* d_inner = nullptr; LabGroup* d_groups = nullptr;
+    LabPNode* d_inner = nullptr; LabGroup* d_groups = nullptr; LabPNode32* d_inner32 = nullptr;
     LabW1Scene w1{};
     uint32_t n_inner = 0, n_groups = 0, stack_need = 0;
 };
@@ -510,8 +653,22 @@ int rt1w_lab_create(rt1w_context* c, const rt1w_scene* s, rt1w_lab** out) {
     std::vector<LabPNode> inner; std::vector<LabGroup> groups;
     l->w1_ok = build_w1(s->flat_nodes, s->flat_root, inner, groups, l->w1, l->w1_why) && s->stack_need <= (uint32_t)LAB_W1_STACK;
     if (l->w1_ok) {
-        if (!lab_upload(&l->d_inner, inner) || !lab_upload(&l->d_groups, groups)) { rt1w_lab_destroy(l); return RT1W_ERR_DEVICE; }
-        l->w1.inner = l->d_inner; l->w1.groups = l->d_groups;
+        std::vector<LabPNode32> inner32(inner.size());
+        for (size_t i = 0; i < inner.size(); ++i) {
+            memset(&inner32[i], 0, sizeof(LabPNode32));
+            for (int a = 0; a < 6; ++a) {
+                const bool is_min = a < 3;
+                for (int side = 0; side < 2; ++side) {
+                    const double x = side ? inner[i].rb[a] : inner[i].lb[a];
+                    float f = (float)x;
+                    if (is_min ? ((double)f > x) : ((double)f < x)) f = nextafterf(f, is_min ? -INFINITY : INFINITY); /* outward */
+                    (side ? inner32[i].rb : inner32[i].lb)[a] = f;
+                }
+            }
+            inner32[i].l = inner[i].l; inner32[i].r = inner[i].r;
+        }
+        if (!lab_upload(&l->d_inner, inner) || !lab_upload(&l->d_groups, groups) || !lab_upload(&l->d_inner32, inner32)) { rt1w_lab_destroy(l); return RT1W_ERR_DEVICE; }
+        l->w1.inner = l->d_inner; l->w1.groups = l->d_groups; l->w1.inner32 = l->d_inner32;
         l->n_inner = (uint32_t)inner.size(); l->n_groups = (uint32_t)groups.size(); l->stack_need = s->stack_need;
     }
     *out = l;
@@ -525,6 +682,7 @@ void rt1w_lab_destroy(rt1w_lab* l) {
     if (l->d_counter) (void)hipFree(l->d_counter);
     if (l->d_inner) (void)hipFree(l->d_inner);
     if (l->d_groups) (void)hipFree(l->d_groups);
+    if (l->d_inner32) (void)hipFree(l->d_inner32);
     if (l->ev0) (void)hipEventDestroy(l->ev0);
     if (l->ev1) (void)hipEventDestroy(l->ev1);
     if (l->stream) (void)hipStreamDestroy(l->stream);
@@ -535,6 +693,31 @@ int rt1w_lab_info(const rt1w_lab* l, uint32_t out[4]) {
     if (!l || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
     out[0] = l->w1_ok ? 1u : 0u; out[1] = l->n_inner; out[2] = l->n_groups; out[3] = (uint32_t)l->variant;
     if (!l->w1_ok) rt1w::set_error("W1 not available for this scene: " + l->w1_why);
+    return RT1W_OK;
+}
+
+/* out_ms[4] = kernel ms of {own record, quad-shared} x {independent, dependent} indices; grid = blocks_per_cu x CUs of 256 threads */
+int rt1w_lab_gather_probe(rt1w_lab* l, uint32_t iters, uint32_t blocks_per_cu, double out_ms[4], uint64_t* records_per_launch) {
+    if (!l || !out_ms) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    const int grid = l->cus * (int)(blocks_per_cu ? blocks_per_cu : 4u);
+    for (int v = 0; v < 4; ++v) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(l->ev0, l->stream);
+            if (v == 0) hipLaunchKernelGGL((lab_gather_kernel<0, 0>), dim3(grid), dim3(256), 0, l->stream, l->view.nodes, l->view.n_nodes, iters, l->d_counter);
+            else if (v == 1) hipLaunchKernelGGL((lab_gather_kernel<1, 0>), dim3(grid), dim3(256), 0, l->stream, l->view.nodes, l->view.n_nodes, iters, l->d_counter);
+            else if (v == 2) hipLaunchKernelGGL((lab_gather_kernel<0, 1>), dim3(grid), dim3(256), 0, l->stream, l->view.nodes, l->view.n_nodes, iters, l->d_counter);
+            else hipLaunchKernelGGL((lab_gather_kernel<1, 1>), dim3(grid), dim3(256), 0, l->stream, l->view.nodes, l->view.n_nodes, iters, l->d_counter);
+            (void)hipEventRecord(l->ev1, l->stream);
+            if (!lab_ok(hipGetLastError(), "launch(gather)") || !lab_ok(hipEventSynchronize(l->ev1), "gather kernel")) return RT1W_ERR_DEVICE;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, l->ev0, l->ev1);
+            if (ms < best) best = ms;
+        }
+        out_ms[v] = best;
+    }
+    if (records_per_launch) *records_per_launch = (uint64_t)grid * 256ull * iters;
     return RT1W_OK;
 }
 
@@ -576,13 +759,18 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (!l || !l->d_rays) { rt1w::set_error("no rays set"); return RT1W_ERR_STATE; }
     if (mode == 1 && !l->w1_ok) { rt1w::set_error("W1 not available for this scene: " + l->w1_why); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 2 && (!l->w1_ok || l->n_inner > LAB_LDS_INNER || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with LDS-resident inner records: scene too big or W1 unavailable"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 2) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode < 0 || mode > 5) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
     int per_cu = 0;
     const void* fn = nullptr;
     if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
+    else if (mode == 3) fn = l->variant == 5 ? (const void*)lab_trace_w0q<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0q<RtCfgV3> : (const void*)lab_trace_w0q<RtCfgV2>);
+    else if (mode == 4) fn = (const void*)lab_trace_w1<false, true>;
+    else if (mode == 5) fn = (const void*)lab_trace_w1<true, true>;
     else fn = mode == 1 ? (const void*)lab_trace_w1<false> : (const void*)lab_trace_w1<true>;
     if (!lab_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_BLOCK, 0), "occupancy")) return RT1W_ERR_DEVICE;
     if (per_cu < 1) per_cu = 1;
@@ -596,8 +784,14 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
             if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else hipLaunchKernelGGL(lab_trace_w0<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+        } else if (mode == 3) {
+            if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0q<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0q<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else hipLaunchKernelGGL(lab_trace_w0q<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
         } else {
-            if (mode == 1) hipLaunchKernelGGL(lab_trace_w1<false>, dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
+            if (mode == 5) hipLaunchKernelGGL((lab_trace_w1<true, true>), dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
+            else if (mode == 4) hipLaunchKernelGGL((lab_trace_w1<false, true>), dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
+            else if (mode == 1) hipLaunchKernelGGL(lab_trace_w1<false>, dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
             else hipLaunchKernelGGL(lab_trace_w1<true>, dim3(grid), dim3(LAB_W1_BLOCK), 0, l->stream, l->w1, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, l->n_inner);
         }
         (void)hipEventRecord(l->ev1, l->stream);
@@ -606,7 +800,7 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
         (void)hipEventElapsedTime(&ms, l->ev0, l->ev1);
         if (ms < best) best = ms;
     }
-    if (mode >= 1) { /* rays the pair walk handed back: the product's walk answers them (not timed: a handful per million) */
+    if (mode == 1 || mode == 2 || mode == 4 || mode == 5) { /* rays the pair walk handed back: the product's walk answers them (not timed: a handful per million) */
         const unsigned g2 = (unsigned)((l->n_rays + RT_BLOCK - 1) / RT_BLOCK);
         if (l->variant == 5) hipLaunchKernelGGL(lab_fallback<RtCfgV5>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);
         else hipLaunchKernelGGL(lab_fallback<RtCfgV2>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);

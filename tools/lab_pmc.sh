@@ -21,7 +21,7 @@ n = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "lab_trace_w0" if "lab_trace_w0" in k else ("lab_trace_w1<1>" if ("lab_trace_w1" in k and "Lb1" in k) else ("lab_trace_w1<0>" if "lab_trace_w1" in k else None))
+        k = "lab_trace_w0q" if "lab_trace_w0q" in k else "lab_trace_w0" if "lab_trace_w0" in k else ("lab_trace_w1<" + ",".join("1" if x == "Lb1" else "0" for x in __import__("re").findall(r"Lb[01]", k)[:2]) + ">" if "lab_trace_w1" in k else None)
         if k:
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 with open("$OUT/summary.txt", "w") as o:

@@ -21,6 +21,7 @@ L.rt1w_lab_destroy.argtypes = [_P]
 L.rt1w_lab_info.argtypes = [_P, C.POINTER(C.c_uint32 * 4)]
 L.rt1w_lab_dump_rays.argtypes = [_P, C.POINTER(rt.RenderParams), C.c_uint32, _P]
 L.rt1w_lab_set_rays.argtypes = [_P, _P, C.c_uint64]
+L.rt1w_lab_gather_probe.argtypes = [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint64)]
 L.rt1w_lab_trace.argtypes = [_P, C.c_int, C.POINTER(C.c_uint32 * 4), C.c_int, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_uint64 * 8)]
 
 
@@ -81,6 +82,13 @@ def main():
     lab = Lab(ctx)
     print(f"arm {arm} {W}x{H}x{spp}, nodes {sc.info()['n_nodes']}, product walk variant V{lab.variant}; W1: "
           + (f"{lab.n_inner} inner pair records + {lab.n_groups} leaf groups" if lab.w1_ok else f"unavailable ({lab.w1_why})"), flush=True)
+    if "--gather" in sys.argv:
+        for bpc in (2, 4, 8):
+            ms = (C.c_double * 4)()
+            nrec = C.c_uint64()
+            rt._ck(L.rt1w_lab_gather_probe(lab._h, 2000, bpc, C.byref(ms), C.byref(nrec)))
+            print(f"gather probe, {bpc} workgroups/CU, {nrec.value / 1e6:.0f} M records of 64 B from {sc.info()['n_nodes']} nodes: "
+                  + "  ".join(f"{lbl} {nrec.value / m / 1e6:7.1f} Grec/s" for lbl, m in zip(("own/indep", "quad/indep", "own/dep", "quad/dep"), ms)), flush=True)
     rays = lab.dump_rays(W, H, spp, bounces)
     sets = []
     for b in range(bounces):
@@ -97,6 +105,8 @@ def main():
         n = len(v)
         print(f"{name:26s} {n:9d} rays | W0 {n / base['ms'] / 1e3:8.1f} Mrays/s  steps/ray {base['stats'][0] / n:6.1f}  wave-steps/64 rays "
               f"{base['stats'][1] * 64 / n:7.1f}", end="", flush=True)
+        q = min((lab.trace(3, refill=rf) for rf in ((16, 32, 48, 60) if sweep else (32, 48))), key=lambda r: r["ms"])
+        print(f" | W0q {n / q['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / q['ms']:.2f}x) hits equal W0: {same_hits(base, q)}", end="", flush=True)
         if lab.w1_ok:
             best = None
             for votes in ((8, 24, 40, 56) if sweep else (24,)):
@@ -113,14 +123,21 @@ def main():
                   f"wave-steps/64 rays box {st[1] * 64 / n:6.1f} leaf {st[3] * 64 / n:6.1f}  handed back {int((r['flags'] & 1).sum())}  hits equal W0: {ok}", end="")
         if lab.w1_ok and "--probe" in sys.argv:
             # what bounds the walk?  occupancy sweep of W0 / W1, and W1 with the inner records in LDS instead of behind the L1
-            for mode, label in ((0, "W0"), (1, "W1"), (2, "W1 + inner records in LDS")):
-                for bpc in (1, 2, 3):
+            for mode, label in ((0, "W0"), (1, "W1"), (2, "W1 + inner records in LDS"), (4, "W1c"), (5, "W1c + inner records in LDS")):
+                for bpc in (1, 2, 3, 4, 5):
                     try:
                         r = lab.trace(mode, refill=48, votes=24, blocks_per_cu=bpc, want_hits=False)
                     except rt.Rt1wError as e:
                         print(f"      {label}: {e}")
                         break
-                    print(f"      {label:28s} {bpc} workgroups/CU: {n / r['ms'] / 1e3:8.1f} Mrays/s")
+                    print(f"      {label:28s} {r['stats'][7]} workgroups/CU: {n / r['ms'] / 1e3:8.1f} Mrays/s")
+                    if r['stats'][7] < bpc:
+                        break
+        if lab.w1_ok:
+            for votes in (8, 24, 40):
+                c = min((lab.trace(4, refill=rf, votes=votes) for rf in (32, 48)), key=lambda r: r["ms"])
+                print(f"\n      W1c (f32 inner boxes, 4 loads per pair) votes {votes}: {n / c['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / c['ms']:.2f}x)  wave-steps/64 rays box "
+                      f"{c['stats'][1] * 64 / n:6.1f} leaf {c['stats'][3] * 64 / n:6.1f}  inner/ray {c['stats'][0] / n:5.1f}  workgroups/CU {c['stats'][7]}  hits equal W0: {same_hits(base, c)}", end="")
         print(flush=True)
     lab.close()
     ctx.close()
