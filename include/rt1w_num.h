@@ -223,6 +223,26 @@ RT_HD RtRng rt_rng_build(uint64_t build_seed) {
     return rt_rng_make((uint32_t)build_seed, (uint32_t)(build_seed >> 32), 0u, 0u, RT_DOMAIN_BUILD);
 }
 
+/* Position of a stream, small enough to keep around (3 numbers), and the way back to it: the blocks are a pure function of
+ * (key, counter), so the buffered words are regenerated.  Used where a stretch of code may have to be redone from the same
+ * random state (the phased walk's restart, csrc/rt_walk2.h). */
+struct RtRngMark { uint32_t blk, left, bv; };
+RT_HD RtRngMark rt_rng_mark(const RtRng& r) { RtRngMark m; m.blk = r.blk; m.left = r.left; m.bv = r.bv; return m; }
+RT_HD void rt_rng_rewind(RtRng& r, RtRngMark m) {
+    /* A = the last `left` words of block (blk - 1 - bv), B = block blk - 1 when bv */
+    if (m.left > 0u) {
+        r.blk = m.blk - 1u - m.bv;
+        rt_rng_gen_b(r);
+        const uint32_t w0 = r.b0, w1 = r.b1, w2 = r.b2, w3 = r.b3;
+        r.a0 = m.left == 4u ? w0 : (m.left == 3u ? w1 : (m.left == 2u ? w2 : w3));
+        r.a1 = m.left == 4u ? w1 : (m.left == 3u ? w2 : w3);
+        r.a2 = m.left == 4u ? w2 : w3;
+        r.a3 = w3;
+    }
+    if (m.bv) { r.blk = m.blk - 1u; rt_rng_gen_b(r); }
+    r.blk = m.blk; r.left = m.left; r.bv = m.bv;
+}
+
 /* ---- unchecked takes: the caller has reserved ---- */
 RT_HD void rt_rng_pull(RtRng& r) { /* A is empty: B becomes A */
     RT_RNG_ASSERT(r.bv);

@@ -162,7 +162,7 @@ struct rt1w_context {
     WfCounters* wf_counters = nullptr; unsigned long long* wf_hcounters = nullptr;
     size_t wf_cap = 0;
     WfRecs wf_recs = {nullptr, 0.0, 1.0}; void* d_wf_recs = nullptr; /* walk records of the big scenes (null: not eligible) */
-    int wf_grid_trace[18] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
+    int wf_grid_trace[22] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
     uint32_t stack_need = 0;
     int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
     void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays */
@@ -457,6 +457,8 @@ static wf_trace_t const g_wf_trace[3][2][2] = {
     {{wf_trace<RtCfgV4, false, 16>, wf_trace<RtCfgV4, false, 32>}, {wf_trace<RtCfgV4, true, 16>, wf_trace<RtCfgV4, true, 32>}}};
 static wf_trace_t const g_wf_trace_lds[3][2] = {{wf_trace_lds<RtCfgV2, false>, wf_trace_lds<RtCfgV2, true>}, {wf_trace_lds<RtCfgV3, false>, wf_trace_lds<RtCfgV3, true>},
                                                 {wf_trace_lds<RtCfgV4, false>, wf_trace_lds<RtCfgV4, true>}};
+/* the plain trace kernels (the product's own walk by itself): V2, V3, V4, and V5 for scenes without wrappers */
+static wf_trace_t const g_wf_trace_plain[4] = {wf_trace_plain<RtCfgV2>, wf_trace_plain<RtCfgV3>, wf_trace_plain<RtCfgV4>, wf_trace_plain<RtCfgV5>};
 static wf_shade_t const g_wf_shade[3] = {wf_shade<RtCfgV2>, wf_shade<RtCfgV3>, wf_shade<RtCfgV4>};
 typedef void (*wf_finish_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
 static wf_finish_t const g_wf_finish[3] = {wf_finish<RtCfgV2>, wf_finish<RtCfgV3>, wf_finish<RtCfgV4>};
@@ -498,12 +500,18 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
         if (!hip_ok(hipMalloc((void**)&c->wf_counters, sizeof(WfCounters)), "hipMalloc(counters)") ||
             !hip_ok(hipHostMalloc((void**)&c->wf_hcounters, 2 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(counters)")) return RT1W_ERR_NOMEM;
     }
-    const bool lds_recs = c->n_nodes <= RT_WF_LDS_NODES && c->stack_need <= 16u && !getenv("RT1W_WF_NO_LDS");
+    /* trace kernel: the plain one (the product's walk by itself; default since round 3), or the vote-scheduled one of round 2
+     * (RT1W_WF_TRACE=vote: kept for the A/B, profiles/r03_wavefront_*) */
+    const char* wf_trace_env = getenv("RT1W_WF_TRACE");
+    const bool plain_trace = !(wf_trace_env && wf_trace_env[0] == 'v');
+    const bool lds_recs = !plain_trace && c->n_nodes <= RT_WF_LDS_NODES && c->stack_need <= 16u && !getenv("RT1W_WF_NO_LDS");
     const int tblock = lds_recs ? RT_WF_LDS_BLOCK : RT_BLOCK;
-    const wf_trace_t trace = lds_recs ? g_wf_trace_lds[v - 2][c->scope_depth > 0u ? 1 : 0]
+    const wf_trace_t trace = plain_trace ? g_wf_trace_plain[L.variant == 5 ? 3 : v - 2]
+                           : lds_recs ? g_wf_trace_lds[v - 2][c->scope_depth > 0u ? 1 : 0]
                                       : g_wf_trace[v - 2][c->scope_depth > 0u ? 1 : 0][c->stack_need <= 16u ? 0 : 1];
     const wf_shade_t shade = g_wf_shade[v - 2];
-    const int gi = lds_recs ? 12 + (v - 2) * 2 + (c->scope_depth > 0u ? 1 : 0) : (v - 2) * 4 + (c->scope_depth > 0u ? 2 : 0) + (c->stack_need <= 16u ? 0 : 1);
+    const int gi = plain_trace ? 18 + (L.variant == 5 ? 3 : v - 2)
+                 : lds_recs ? 12 + (v - 2) * 2 + (c->scope_depth > 0u ? 1 : 0) : (v - 2) * 4 + (c->scope_depth > 0u ? 2 : 0) + (c->stack_need <= 16u ? 0 : 1);
     if (!c->wf_grid_trace[gi] || !c->wf_grid_shade[v - 2]) {
         int per_cu = 0, per_cu_s = 0;
         hipDeviceProp_t prop;
@@ -522,7 +530,9 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
             !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
         c->wf_grid_finish[v - 2] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
     }
-    const uint32_t wf_bounces = f.max_depth < RT_WF_BOUNCES ? f.max_depth : RT_WF_BOUNCES;
+    uint32_t wf_bounces_want = plain_trace ? RT_WF_BOUNCES_PLAIN : RT_WF_BOUNCES;
+    if (const char* e = getenv("RT1W_WF_BOUNCES")) { const int x = atoi(e); if (x >= 1 && x <= (int)WF_MAX_BOUNCES) wf_bounces_want = (uint32_t)x; }
+    const uint32_t wf_bounces = f.max_depth < wf_bounces_want ? f.max_depth : wf_bounces_want;
     if (!hip_ok(hipMemsetAsync(&c->wf_counters->segs, 0, sizeof(unsigned long long), l.stream), "counter reset")) return RT1W_ERR_DEVICE;
     (void)hipEventRecord(l.ev0, l.stream);
     for (uint32_t ch = 0; ch < f.n_chunks; ++ch) {
@@ -561,7 +571,7 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
         (void)hipEventElapsedTime(&ms, l.ev0, l.ev1);
         stats->paths = npix * f.spp; stats->segments = c->wf_hcounters[1]; stats->kernel_ms = ms;
         stats->chunk = f.chunk; stats->n_chunks = f.n_chunks; stats->grid = (uint32_t)grid_t; stats->block = (uint32_t)tblock;
-        stats->variant = (uint32_t)v; stats->sorted = 8u | (lds_recs ? 2u : 0u); /* bit 3: wavefront form; bit 1: walk records in LDS */
+        stats->variant = (uint32_t)v; stats->sorted = 8u | (lds_recs ? 2u : 0u) | (plain_trace ? 64u : 0u); /* bit 3: wavefront form; bit 1: walk records in LDS; bit 6: plain trace kernel */
     }
     return RT1W_OK;
 }

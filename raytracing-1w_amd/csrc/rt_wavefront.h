@@ -379,6 +379,96 @@ __global__ __launch_bounds__(RT_WF_LDS_BLOCK) void wf_trace_lds(RtSceneView sc, 
     wf_trace_body<Cfg, WRAP, RT_WF_LDS_BLOCK, true>(sc, f, q, ctr, bounce, s0, recs, stack_mem, lrecs);
 }
 
+/* PLAIN TRACE KERNEL (round 3).  The trace-only harness (walk_lab.hip) showed that the product's own one-entry-per-step walk,
+ * run by itself -- walk state only, idle lanes refilled from the ray list once 32 wait -- answers 1.9 G rays/s on final_scene's
+ * rays and 3.2 G rays/s on random_scene's, where the vote-scheduled kernel above does 0.7 G rays/s and the megakernel's whole
+ * step 1.1 / 2.4 G segments/s (profiles/r03_lab_*).  So this is that loop on the queue: per lane rt_walk_begin / rt_walk_step /
+ * rt_walk_done of rt_core.h on the 64-byte hot halves of the flat nodes, results written at the refill.  Same visits, same
+ * order, same operands per lane as the megakernel's walk: same bits. */
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, 3) void wf_trace_plain(RtSceneView sc, RtFrame f, WfQueue q, WfCounters* __restrict__ ctr, uint32_t bounce, uint32_t s0,
+                                                             WfRecs recs) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    (void)recs;
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    const RtGlobalNodes ns{sc.nodes};
+    const unsigned long long n = ctr->n[bounce];
+    if (n == 0ull) return;
+    const unsigned long long total_waves = (unsigned long long)gridDim.x * (RT_BLOCK / 64);
+    unsigned long long w_next = 0, w_end = 0;
+    bool exhausted = false, have = false, unsent = false;
+    unsigned long long slot = 0;
+    RtWalk k;
+    RtRng rng = rt_rng_make(0u, 0u, 0u, 0u, 0u);
+    unsigned long long segs = 0;
+    for (;;) {
+        {
+            const unsigned long long idle = __ballot(!have);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (!exhausted && (n_idle >= RT_WF_REFILL)) {
+                if (w_next >= w_end) {
+                    unsigned long long base = 0, batch = 0;
+                    if ((threadIdx.x & 63u) == 0u) {
+                        const unsigned long long seen = __hip_atomic_load(&ctr->next[bounce], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long remaining = n > seen ? n - seen : 0ull;
+                        batch = remaining / (4ull * total_waves);
+                        batch = batch > 2048ull ? 2048ull : (batch < 64ull ? 64ull : (batch & ~63ull));
+                        base = atomicAdd(&ctr->next[bounce], batch);
+                    }
+                    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+                    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t)batch);
+                    base = ((unsigned long long)bhi << 32) | blo;
+                    w_next = base < n ? base : n;
+                    w_end = base + nb < n ? base + nb : n;
+                    if (w_next >= w_end) exhausted = true;
+                }
+                if (unsent) {
+                    q.f[WF_HIT_T * q.cap + slot] = k.best_t;
+                    q.u[WU_PRIM * q.cap + slot] = k.best_prim;
+                    q.u[WU_SCOPE * q.cap + slot] = k.best_scope;
+                    if (Cfg::media) wf_rng_store(rng, q, slot);
+                    unsent = false;
+                }
+                const unsigned long long avail = w_end - w_next;
+                if (avail != 0ull) {
+                    const uint32_t rank = lane_prefix(idle);
+                    const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
+                    if (!have && rank < take) {
+                        slot = w_next + rank;
+                        RtRay ray;
+                        ray.o = rt_v3(q.f[WF_OX * q.cap + slot], q.f[WF_OY * q.cap + slot], q.f[WF_OZ * q.cap + slot]);
+                        ray.d = rt_v3(q.f[WF_DX * q.cap + slot], q.f[WF_DY * q.cap + slot], q.f[WF_DZ * q.cap + slot]);
+                        ray.time = q.f[WF_TIME * q.cap + slot];
+                        if (Cfg::media) rng = wf_rng_load(f, s0, q.u[WU_PID * q.cap + slot], q, slot); /* ConstantMedium draws while being traversed */
+                        stk.sp = 0;
+                        rt_walk_begin(k, sc.root, ray, 0.001, RT_INF, stk); /* main.rs:62: world.hit(ray, 0.001, INFINITY) */
+                        have = true;
+                        segs += 1ull;
+                    }
+                    w_next += take;
+                }
+            }
+            if (!RT_WAVE_ANY(have)) {
+                if (exhausted) break;
+                continue;
+            }
+        }
+        if (have) {
+            rt_walk_step<Cfg, true>(sc, ns, k, rng, stk);
+            if (rt_walk_done(k, stk)) { have = false; unsent = true; }
+        }
+    }
+    if (unsent) {
+        q.f[WF_HIT_T * q.cap + slot] = k.best_t;
+        q.u[WU_PRIM * q.cap + slot] = k.best_prim;
+        q.u[WU_SCOPE * q.cap + slot] = k.best_scope;
+        if (Cfg::media) wf_rng_store(rng, q, slot);
+    }
+    if (segs) atomicAdd(&ctr->segs, segs);
+}
+
 /* one bounce of shading: grid-stride over the queue's slots (coalesced), survivors appended to `qo` */
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK) void wf_shade(RtSceneView sc, RtFrame f, WfQueue qi, WfQueue qo, WfCounters* __restrict__ ctr, uint32_t bounce,
@@ -443,6 +533,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_shade(RtSceneView sc, RtFrame f, 
  * to its end with the megakernel's own rt_path_step (plain stack walk), the lane taking the next path when its own ends. */
 #ifndef RT_WF_BOUNCES
 #define RT_WF_BOUNCES 6u
+#endif
+#ifndef RT_WF_BOUNCES_PLAIN
+#define RT_WF_BOUNCES_PLAIN 12u /* with the plain trace kernel (measured: profiles/r03_wavefront_bounces.txt) */
 #endif
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, 3) void wf_finish(RtSceneView sc, RtFrame f, WfQueue q, WfCounters* __restrict__ ctr, uint32_t bounce, uint32_t s0,

@@ -15,6 +15,8 @@
  * Walks:
  *   mode 0  W0: the product's stack walk (rt_walk_begin / rt_walk_step of rt_core.h), one stack entry per step.
  *   mode 3  W0q: W0 with the node records fetched by quads (four lanes share each 64-byte access) and transposed with DPP.
+ *   mode 6  W2: the phased walk of rt_walk2.h -- W1's two phases for EVERY scene (wrappers, media, rects, nested BVHs), inner boxes
+ *           in f32 rounded outward; what the product's stack-walk kernels are to run.
  *   mode 1  W1: pair walk in two phases (see below) -- media-free, wrapper-free scenes whose primitives sit under
  *           BVHChild::One or under a two-object BVHChild::Two (what BVHNode::new builds, bvh.rs:63-79).
  *
@@ -30,6 +32,7 @@
 
 #include "rt1w.h"
 #include "rt_kernel_sorted.h" /* rt_core.h, LdsStack, lane_prefix */
+#include "rt_walk2.h"
 #include "scene.h"
 #include "walk_lab.h"
 
@@ -503,6 +506,84 @@ __global__ __launch_bounds__(LAB_W1_BLOCK, LDS_INNER ? (F32 ? 3 : 2) : (F32 ? 4 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------- W2 -- */
+
+/* the phased walk of rt_walk2.h (every scene): the wave votes for box work or leaf work; lanes refill like W0's */
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w2(RtSceneView sc, RtW2View w2, const LabRay* __restrict__ rays, unsigned long long n,
+                                                            LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
+                                                            uint32_t leaf_votes, unsigned long long* stats) {
+    __shared__ uint32_t s_ref[RT_W2_STACK * RT_BLOCK];
+    __shared__ float s_ent[RT_W2_STACK * RT_BLOCK];
+    __shared__ uint32_t s_q[RT_W2_QCAP * RT_BLOCK];
+    RtW2Stack<RT_BLOCK> stk;
+    stk.ref = s_ref + threadIdx.x; stk.ent = s_ent + threadIdx.x; stk.q = s_q + threadIdx.x;
+    stk.sp = 0; stk.qh = 0u; stk.qn = 0u;
+    RtGlobalNodes ns{sc.nodes};
+    RtWalk k;
+    RtW2Lane L; L.cur = RT_W2_NONE; L.nan_seen = false;
+    RtRng rng = rt_rng_make(0u, 0u, 0u, 0u, RT_DOMAIN_RENDER);
+    RtRngMark mark = rt_rng_mark(rng);
+    RtRay w; w.o = w.d = rt_v3(0, 0, 0); w.time = 0.0;
+    unsigned long long mine = ~0ull;
+    bool walking = false, exhausted = false, redone = false;
+    unsigned long long n_box = 0, n_leaf = 0, w_box = 0, w_leaf = 0, n_other = 0, n_redo = 0;
+    for (;;) {
+        {
+            const bool idle = !walking;
+            const unsigned long long idle_m = __ballot(idle && !exhausted);
+            if ((uint32_t)__popcll(idle_m) >= refill_idle || __ballot(walking) == 0ull) {
+                if (idle && !exhausted && mine != ~0ull) {
+                    LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = redone ? 1u : 0u; out[mine] = h; mine = ~0ull;
+                }
+                const unsigned long long idx = lab_fetch(idle && !exhausted, counter);
+                if (idle && !exhausted) {
+                    if (idx < n) {
+                        const LabRay r = rays[idx];
+                        w.o = rt_v3(r.o[0], r.o[1], r.o[2]); w.d = rt_v3(r.d[0], r.d[1], r.d[2]); w.time = r.time;
+                        rng = rt_rng_make((uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u, RT_DOMAIN_RENDER);
+                        mark = rt_rng_mark(rng);
+                        rt_w2_begin(w2, L, k, w, 0.001, RT_INF, stk);
+                        mine = idx; walking = true; redone = false;
+                    } else exhausted = true;
+                }
+            }
+        }
+        if (__ballot(walking) == 0ull) break;
+        const bool can_box = walking && rt_w2_is_boxwork(L.cur) && stk.qn + 2u <= (uint32_t)RT_W2_QCAP;
+        const bool can_leaf = walking && (stk.qn > 0u || rt_w2_is_other(L.cur));
+        const uint32_t nb = (uint32_t)__popcll(__ballot(can_box)), nl = (uint32_t)__popcll(__ballot(can_leaf));
+        if (nl >= leaf_votes || nb == 0u) {
+            if (can_leaf) {
+                if (stk.qn > 0u) { rt_w2_group_step<Cfg>(sc, ns, L, k, stk); ++n_leaf; }
+                else { rt_w2_other_step<Cfg>(sc, ns, w2, L, k, rng, stk); ++n_other; }
+            }
+            ++w_leaf;
+        } else {
+            if (can_box) { rt_w2_box_step<RtW2Stack<RT_BLOCK>, RT_BLOCK>(w2, L, k, stk); ++n_box; }
+            ++w_box;
+        }
+        if (walking) {
+            if (L.nan_seen) { /* the closest hit turned NaN: the ray is handed back (flag bit 0) and answered by the classic walk */
+                L.cur = RT_W2_NONE; L.nan_seen = false; redone = true; ++n_redo;
+                stk.sp = 0; stk.qn = 0u;
+                walking = false;
+            } else {
+                rt_w2_refetch<RtW2Stack<RT_BLOCK>, RT_BLOCK>(L, k, stk);
+                if (rt_w2_done(L, stk)) walking = false;
+            }
+        }
+    }
+    if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = redone ? 1u : 0u; out[mine] = h; }
+    if (stats) {
+        atomicAdd(&stats[0], n_box);
+        atomicAdd(&stats[2], n_leaf);
+        atomicAdd(&stats[4], n_other);
+        atomicAdd(&stats[5], n_redo);
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&stats[1], w_box); atomicAdd(&stats[3], w_leaf); }
+    }
+}
+
 /* rays W1 could not answer (flag bit 0): the product's walk from scratch, one thread per ray */
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, 2) void lab_fallback(RtSceneView sc, const LabRay* __restrict__ rays, unsigned long long n, LabHit* __restrict__ out) {
@@ -541,6 +622,10 @@ struct rt1w_lab {
     LabPNode* d_inner = nullptr; LabGroup* d_groups = nullptr; LabPNode32* d_inner32 = nullptr;
     LabW1Scene w1{};
     uint32_t n_inner = 0, n_groups = 0, stack_need = 0;
+    /* W2 */
+    RtW2Inner* d_w2_inner = nullptr; uint32_t* d_w2_wref = nullptr;
+    RtW2View w2{};
+    bool w2_ok = false;
 };
 
 namespace {
@@ -671,6 +756,14 @@ int rt1w_lab_create(rt1w_context* c, const rt1w_scene* s, rt1w_lab** out) {
         l->w1.inner = l->d_inner; l->w1.groups = l->d_groups; l->w1.inner32 = l->d_inner32;
         l->n_inner = (uint32_t)inner.size(); l->n_groups = (uint32_t)groups.size(); l->stack_need = s->stack_need;
     }
+    {
+        std::vector<RtW2Inner> w2i; std::vector<uint32_t> wref; uint32_t root_ref = 0u;
+        rt_walk2_build(s->flat_nodes, s->flat_root, w2i, wref, root_ref);
+        if (!lab_upload(&l->d_w2_inner, w2i) || !lab_upload(&l->d_w2_wref, wref)) { rt1w_lab_destroy(l); return RT1W_ERR_DEVICE; }
+        l->w2.inner = l->d_w2_inner; l->w2.wref = l->d_w2_wref; l->w2.root = root_ref; l->w2.n_inner = (uint32_t)w2i.size();
+        l->w2_ok = s->stack_need + 2u <= (uint32_t)RT_W2_STACK;
+        l->stack_need = s->stack_need;
+    }
     *out = l;
     return RT1W_OK;
 }
@@ -683,6 +776,8 @@ void rt1w_lab_destroy(rt1w_lab* l) {
     if (l->d_inner) (void)hipFree(l->d_inner);
     if (l->d_groups) (void)hipFree(l->d_groups);
     if (l->d_inner32) (void)hipFree(l->d_inner32);
+    if (l->d_w2_inner) (void)hipFree(l->d_w2_inner);
+    if (l->d_w2_wref) (void)hipFree(l->d_w2_wref);
     if (l->ev0) (void)hipEventDestroy(l->ev0);
     if (l->ev1) (void)hipEventDestroy(l->ev1);
     if (l->stream) (void)hipStreamDestroy(l->stream);
@@ -761,7 +856,8 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (mode == 2 && (!l->w1_ok || l->n_inner > LAB_LDS_INNER || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with LDS-resident inner records: scene too big or W1 unavailable"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 5) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (mode == 6 && !l->w2_ok) { rt1w::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode < 0 || mode > 6) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
@@ -769,6 +865,7 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     const void* fn = nullptr;
     if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
     else if (mode == 3) fn = l->variant == 5 ? (const void*)lab_trace_w0q<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0q<RtCfgV3> : (const void*)lab_trace_w0q<RtCfgV2>);
+    else if (mode == 6) fn = l->variant == 5 ? (const void*)lab_trace_w2<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w2<RtCfgV3> : (const void*)lab_trace_w2<RtCfgV2>);
     else if (mode == 4) fn = (const void*)lab_trace_w1<false, true>;
     else if (mode == 5) fn = (const void*)lab_trace_w1<true, true>;
     else fn = mode == 1 ? (const void*)lab_trace_w1<false> : (const void*)lab_trace_w1<true>;
@@ -784,6 +881,10 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
             if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else hipLaunchKernelGGL(lab_trace_w0<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+        } else if (mode == 6) {
+            if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w2<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1);
+            else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w2<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1);
+            else hipLaunchKernelGGL(lab_trace_w2<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1);
         } else if (mode == 3) {
             if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0q<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0q<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
@@ -799,6 +900,13 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, l->ev0, l->ev1);
         if (ms < best) best = ms;
+    }
+    if (mode == 6) {
+        const unsigned g2 = (unsigned)((l->n_rays + RT_BLOCK - 1) / RT_BLOCK);
+        if (l->variant == 5) hipLaunchKernelGGL(lab_fallback<RtCfgV5>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);
+        else if (l->variant == 3) hipLaunchKernelGGL(lab_fallback<RtCfgV3>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);
+        else hipLaunchKernelGGL(lab_fallback<RtCfgV2>, dim3(g2), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits);
+        if (!lab_ok(hipStreamSynchronize(l->stream), "fallback kernel")) return RT1W_ERR_DEVICE;
     }
     if (mode == 1 || mode == 2 || mode == 4 || mode == 5) { /* rays the pair walk handed back: the product's walk answers them (not timed: a handful per million) */
         const unsigned g2 = (unsigned)((l->n_rays + RT_BLOCK - 1) / RT_BLOCK);

@@ -133,6 +133,11 @@ def main():
                     print(f"      {label:28s} {r['stats'][7]} workgroups/CU: {n / r['ms'] / 1e3:8.1f} Mrays/s")
                     if r['stats'][7] < bpc:
                         break
+        for votes in (8, 24, 40):
+            c = min((lab.trace(6, refill=rf, votes=votes) for rf in (32, 48)), key=lambda r: r["ms"])
+            st = c["stats"]
+            print(f"\n      W2 phased walk votes {votes:2d}: {n / c['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / c['ms']:.2f}x)  per ray: inner {st[0] / n:5.1f} groups {st[2] / n:5.1f} other {st[4] / n:5.2f}  "
+                  f"wave-steps/64 rays box {st[1] * 64 / n:6.1f} leaf {st[3] * 64 / n:6.1f}  handed back {int((c['flags'] & 1).sum())}  wg/CU {st[7]}  hits equal W0: {same_hits(base, c)}", end="")
         if lab.w1_ok:
             for votes in (8, 24, 40):
                 c = min((lab.trace(4, refill=rf, votes=votes) for rf in (32, 48)), key=lambda r: r["ms"])
