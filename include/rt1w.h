@@ -127,8 +127,11 @@ int rt1w_scene_build_reference(int arm, uint64_t build_seed, double aspect_ratio
  * its own bounding box by rounding would be needed) -- except for MovingSphere: the reference gives a scattered ray
  * time = hit t (src/main.rs:86,145), which moves such a sphere far outside the box the BVH holds for it, so whether it is
  * tested depends on the order.  RT1W_WALK_NEAR_FAR therefore also leaves subtrees with moving spheres in the reference's
- * order; RT1W_WALK_NEAR_FAR_ALL reorders them too and is NOT result-preserving (measured on random_scene: 2 of 9600
- * pixels differ at 4 spp).  Call on a committed scene, before creating contexts. */
+ * order: with it the FRAMES were identical on every scene tested (all eight arms, random graphs), but that is a measurement, not
+ * a proof -- on axis-aligned geometry a box's entry distance can equal a neighbouring face's hit distance, so which of two
+ * edge-on hits survives a prune can depend on the order -- and path lengths (rt1w_stats.segments) may differ for a few rays.
+ * RT1W_WALK_NEAR_FAR_ALL reorders the moving-sphere subtrees too and does change frames (measured on random_scene: 2 of
+ * 9600 pixels differ at 4 spp).  Call on a committed scene, before creating contexts. */
 #define RT1W_WALK_REFERENCE 0u
 #define RT1W_WALK_NEAR_FAR 1u
 #define RT1W_WALK_NEAR_FAR_ALL 2u
@@ -208,7 +211,8 @@ typedef struct rt1w_render_params {
 #define RT1W_PRECISION_F64 0u
 /* the reference's switch set the other way, `type Float = f32`: rays, hit records, boxes, camera and colours in f32 (the
  * random draws are still made in 64 bits and rounded, the elementary functions are evaluated in 64 bits and rounded once, a
- * pixel's samples are summed in f64).  Statistically equal to the f64 frame, not bitwise; generic kernels only. */
+ * pixel's samples are summed in f64).  Statistically equal to the f64 frame, not bitwise.  Runs the generic kernels, or the
+ * f32 build of the scene-specialised kernel where rt1w_context_specialise made one (renders themselves never compile). */
 #define RT1W_PRECISION_F32 1u
 
 typedef struct rt1w_stats {

@@ -36,6 +36,13 @@ struct HostStack {
         e[sp++] = v;
         if (sp > max_sp) max_sp = sp;
     }
+    /* write without moving the top (rt_walk_box's branchless push): the touched slot counts towards the high-water mark and
+     * must lie inside the stack like a push */
+    void poke(int above, uint32_t v) {
+        if (sp + above >= RT_STACK_CAP) { overflow = true; return; }
+        e[sp + above] = v;
+        if (sp + above + 1 > max_sp) max_sp = sp + above + 1;
+    }
     uint32_t pop() { return e[--sp]; }
 };
 }

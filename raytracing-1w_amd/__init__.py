@@ -303,7 +303,7 @@ class Scene:
     def set_walk_order(self, near_far):
         """Opt-in traversal order (rt1w_scene_set_walk_order): False = the reference's left-then-right (default),
         True = near child first in media-free subtrees.  On a committed scene, before creating contexts."""
-        _ck(_lib.rt1w_scene_set_walk_order(self._h, int(near_far)))   # 0 reference, 1 near-far (result-preserving), 2 near-far everywhere
+        _ck(_lib.rt1w_scene_set_walk_order(self._h, int(near_far)))   # 0 reference, 1 near-far (frames identical on all tested scenes, not provably; segment counts may differ), 2 near-far everywhere
         return self
 
     def bvh_topology(self):

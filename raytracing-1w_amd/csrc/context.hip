@@ -165,7 +165,10 @@ struct rt1w_context {
     int wf_grid_trace[22] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
     uint32_t stack_need = 0;
     int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
-    void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays */
+    void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays, built at the first f32 render */
+    bool f32_tried = false, wf_recs_tried = false; std::string wf_recs_error;
+    /* host copies of the flat arrays the two opt-in modes convert on first use (a scene may be destroyed before its contexts) */
+    std::vector<RtNode> h_nodes, h_lights; std::vector<RtMaterial> h_materials; std::vector<RtTexture> h_textures; std::vector<RtPerlin> h_perlin;
     int f32_grid[RT_N_VARIANTS][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
@@ -179,7 +182,8 @@ struct rt1w_context {
     hipModule_t jit32_mod = nullptr;
     hipFunction_t jit32_fn = nullptr;
     int jit32_grid = 0;
-    bool jit32_tried = false;
+    bool jit32_tried = false, jit32_failed = false;
+    std::string jit32_error;
 };
 
 typedef void (*render_kernel_t)(RtSceneView, RtFrame, double*, unsigned long long*);
@@ -210,6 +214,46 @@ bool upload_nodes(void** dst, const std::vector<RtNode>& nodes) {
     memset(&z, 0, sizeof z);
     padded.push_back(z);
     return upload(dst, padded.data(), padded.size() * sizeof(RtNode));
+}
+
+/* RT1W_PRECISION_F32: the f32 copies of the scene arrays, at the first f32 render */
+int ensure_f32_scene(rt1w_context* c) {
+    if (c->f32_scene) return RT1W_OK;
+    if (c->f32_tried) { rt1w::set_error("could not build the single-precision scene arrays"); return RT1W_ERR_DEVICE; }
+    c->f32_tried = true;
+    if (rt1w_internal_f32_create(c->h_nodes.data(), (uint32_t)c->h_nodes.size(), c->h_lights.data(), (uint32_t)c->h_lights.size(),
+                                 c->h_materials.data(), (uint32_t)c->h_materials.size(), c->h_textures.data(), (uint32_t)c->h_textures.size(),
+                                 c->h_perlin.data(), (uint32_t)c->h_perlin.size(), &c->view, &c->f32_scene) != 0) {
+        c->f32_scene = nullptr;
+        rt1w::set_error("could not build the single-precision scene arrays"); return RT1W_ERR_DEVICE;
+    }
+    return RT1W_OK;
+}
+/* RT1W_WAVEFRONT: walk records of the vote-scheduled trace kernel, at the first wavefront render; eligible when every
+ * MovingSphere has the same (time0, time1) */
+int ensure_wf_recs(rt1w_context* c) {
+    if (c->wf_recs.p) return RT1W_OK;
+    if (c->wf_recs_tried) { rt1w::set_error(c->wf_recs_error); return RT1W_ERR_UNSUPPORTED; }
+    c->wf_recs_tried = true;
+    std::vector<WfRec> recs(c->h_nodes.size());
+    bool ok_ms = true, seen = false;
+    double t0 = 0.0, t1 = 1.0;
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const RtNode& n = c->h_nodes[i];
+        WfRec& r = recs[i];
+        r.kind = n.kind; r.b = n.b;
+        for (int k = 0; k < 6; ++k) r.d[k] = n.d[k];
+        r.d[6] = 0.0;
+        if ((n.kind & RT_KIND_MASK) == RT_MSPHERE) {
+            r.d[6] = n.e[2];
+            if (!seen) { t0 = n.e[0]; t1 = n.e[1]; seen = true; }
+            else if (memcmp(&t0, &n.e[0], 8) != 0 || memcmp(&t1, &n.e[1], 8) != 0) ok_ms = false;
+        }
+    }
+    if (!ok_ms) { c->wf_recs_error = "wavefront form: the scene's moving spheres do not share one shutter interval"; rt1w::set_error(c->wf_recs_error); return RT1W_ERR_UNSUPPORTED; }
+    if (!upload(&c->d_wf_recs, recs.data(), recs.size() * sizeof(WfRec))) { c->wf_recs_error = rt1w_last_error(); return RT1W_ERR_DEVICE; }
+    c->wf_recs.p = (const WfRec*)c->d_wf_recs; c->wf_recs.ms_time0 = t0; c->wf_recs.ms_time1 = t1;
+    return RT1W_OK;
 }
 
 int validate(const rt1w_context* c, const rt1w_render_params* p) {
@@ -257,6 +301,7 @@ void lane_destroy(RtLane& l) {
 }
 
 struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32; };
+int specialise_f32(rt1w_context* c, bool allow_compile);
 
 /* what the launch will need, without launching: frame, variant, launch shape */
 int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
@@ -273,6 +318,7 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     L.ref = false; L.f32 = false;
     if (p->precision == RT1W_PRECISION_F32) {
         if (p->flags & (RT1W_RNG_REFERENCE | RT1W_WAVEFRONT | RT1W_LDS_NODES)) { rt1w::set_error("RT1W_PRECISION_F32 has the default kernels only"); return RT1W_ERR_INVALID; }
+        { const int rcf = ensure_f32_scene(c); if (rcf < 0) return rcf; }
         int v = c->variant == 4 ? 3 : c->variant; /* the order-aware variant exists in f64 only */
         if (p->flags >> 8) {
             v = (int)((p->flags >> 8) & 0xFFu) - 1;
@@ -280,23 +326,9 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
                 rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
             }
         }
-        /* a context that runs a scene-specialised kernel in f64 gets the f32 build of that kernel too (kernel cache, else hiprtc) */
-        if (c->jit_fn && !c->jit32_tried && !c->jit32_src.empty()) {
-            c->jit32_tried = true;
-            std::vector<char> code;
-            rt1w::JitInfo info;
-            hipFunction_t fn = nullptr;
-            int per_cu = 0;
-            hipDeviceProp_t prop;
-            if (rt1w::jit_get_code(c->jit32_src, !getenv("RT1W_NO_JIT"), code, info) >= 0 &&
-                hipModuleLoadData(&c->jit32_mod, code.data()) == hipSuccess &&
-                hipModuleGetFunction(&fn, c->jit32_mod, "rt_jit_sorted") == hipSuccess &&
-                hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_SORT_BLOCK, 0) == hipSuccess &&
-                hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
-                c->jit32_fn = fn;
-                c->jit32_grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
-            }
-        }
+        /* a context that runs a scene-specialised kernel in f64 uses the f32 build of that kernel too -- from the kernel
+         * caches only: renders never compile (rt1w_context_specialise does, for both precisions) */
+        if (!(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !(p->flags >> 8)) (void)specialise_f32(c, false);
         if (c->jit32_fn && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !(p->flags >> 8)) {
             L.f32 = true; L.jit = true; L.sorted = true; L.cached = false; L.variant = v; L.grid = c->jit32_grid; L.block = RT_SORT_BLOCK;
             return RT1W_OK;
@@ -447,6 +479,38 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
     return RT1W_OK;
 }
 
+/* the f32 build of the scene-specialised kernel (RT1W_PRECISION_F32): loaded from the kernel caches, compiled only when
+ * `allow_compile` (rt1w_context_specialise).  A failure is remembered with its reason (rt1w_last_error at specialise time). */
+int specialise_f32(rt1w_context* c, bool allow_compile) {
+    if (c->jit32_fn) return RT1W_OK;
+    if (!c->jit_fn || c->jit32_src.empty()) return RT1W_ERR_STATE;
+    if (c->jit32_tried && !allow_compile) return RT1W_ERR_STATE;
+    if (c->jit32_failed) { rt1w::set_error("f32 specialised kernel: " + c->jit32_error); return RT1W_ERR_DEVICE; }
+    c->jit32_tried = true;
+    std::vector<char> code;
+    rt1w::JitInfo info;
+    int rc = rt1w::jit_get_code(c->jit32_src, allow_compile && !getenv("RT1W_NO_JIT"), code, info);
+    if (rc < 0) {
+        if (allow_compile) { c->jit32_failed = true; c->jit32_error = info.message; rt1w::set_error("f32 specialised kernel: " + info.message); }
+        return rc;
+    }
+    hipFunction_t fn = nullptr;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipModuleLoadData(&c->jit32_mod, code.data()), "hipModuleLoadData(f32 specialised kernel)") ||
+        !hip_ok(hipModuleGetFunction(&fn, c->jit32_mod, "rt_jit_sorted"), "hipModuleGetFunction(f32 specialised kernel)") ||
+        !hip_ok(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_SORT_BLOCK, 0), "occupancy query") ||
+        !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) {
+        if (c->jit32_mod) { (void)hipModuleUnload(c->jit32_mod); c->jit32_mod = nullptr; }
+        if (info.from_cache) rt1w::jit_invalidate(info);
+        c->jit32_failed = true; c->jit32_error = rt1w_last_error();
+        return RT1W_ERR_DEVICE;
+    }
+    c->jit32_fn = fn;
+    c->jit32_grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+    return RT1W_OK;
+}
+
 /* ---- wavefront form (rt_wavefront.h) ---- */
 typedef void (*wf_trace_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, WfRecs);
 typedef void (*wf_shade_t)(RtSceneView, RtFrame, WfQueue, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
@@ -475,7 +539,6 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
     if (v < 2) { rt1w::set_error("the wavefront form exists for the stack-walk variants only"); return RT1W_ERR_INVALID; }
     if (npix > RT_WF_PASS_PATHS) { rt1w::set_error("wavefront form: tile larger than one pass (render it in strips)"); return RT1W_ERR_UNSUPPORTED; }
     if (f.max_depth > WF_MAX_BOUNCES) { rt1w::set_error("wavefront form: max_depth above WF_MAX_BOUNCES"); return RT1W_ERR_UNSUPPORTED; }
-    if (!c->wf_recs.p) { rt1w::set_error("wavefront form: the scene's moving spheres do not share one shutter interval"); return RT1W_ERR_UNSUPPORTED; }
     const uint32_t s_pass_max = (uint32_t)(RT_WF_PASS_PATHS / npix);
     const uint32_t n_pass = (f.chunk + s_pass_max - 1u) / s_pass_max;      /* passes per chunk, of (nearly) equal size */
     const uint32_t s_pass = (f.chunk + n_pass - 1u) / n_pass;
@@ -504,6 +567,7 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
      * (RT1W_WF_TRACE=vote: kept for the A/B, profiles/r03_wavefront_*) */
     const char* wf_trace_env = getenv("RT1W_WF_TRACE");
     const bool plain_trace = !(wf_trace_env && wf_trace_env[0] == 'v');
+    if (!plain_trace) { const int rcw = ensure_wf_recs(c); if (rcw < 0) return rcw; } /* the plain kernel reads the flat nodes themselves */
     const bool lds_recs = !plain_trace && c->n_nodes <= RT_WF_LDS_NODES && c->stack_need <= 16u && !getenv("RT1W_WF_NO_LDS");
     const int tblock = lds_recs ? RT_WF_LDS_BLOCK : RT_BLOCK;
     const wf_trace_t trace = plain_trace ? g_wf_trace_plain[L.variant == 5 ? 3 : v - 2]
@@ -685,33 +749,9 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->scope_depth = s->scope_depth;
     c->stack_need = s->stack_need;
     c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth, s->walk_annotated != 0u);
-    if (rt1w_internal_f32_create(s->flat_nodes.data(), (uint32_t)s->flat_nodes.size(), s->flat_lights.data(), (uint32_t)s->flat_lights.size(),
-                                 s->materials.data(), (uint32_t)s->materials.size(), s->textures.data(), (uint32_t)s->textures.size(),
-                                 s->perlin.data(), (uint32_t)s->perlin.size(), &c->view, &c->f32_scene) != 0) {
-        rt1w::set_error("could not build the single-precision scene arrays"); rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
-    }
-    {
-        /* walk records for the wavefront form: eligible when every MovingSphere has the same (time0, time1) */
-        std::vector<WfRec> recs(s->flat_nodes.size());
-        bool ok_ms = true, seen = false;
-        double t0 = 0.0, t1 = 1.0;
-        for (size_t i = 0; i < recs.size(); ++i) {
-            const RtNode& n = s->flat_nodes[i];
-            WfRec& r = recs[i];
-            r.kind = n.kind; r.b = n.b;
-            for (int k = 0; k < 6; ++k) r.d[k] = n.d[k];
-            r.d[6] = 0.0;
-            if ((n.kind & RT_KIND_MASK) == RT_MSPHERE) {
-                r.d[6] = n.e[2];
-                if (!seen) { t0 = n.e[0]; t1 = n.e[1]; seen = true; }
-                else if (memcmp(&t0, &n.e[0], 8) != 0 || memcmp(&t1, &n.e[1], 8) != 0) ok_ms = false;
-            }
-        }
-        if (ok_ms) {
-            if (!upload(&c->d_wf_recs, recs.data(), recs.size() * sizeof(WfRec))) { rt1w_context_destroy(c); return RT1W_ERR_DEVICE; }
-            c->wf_recs.p = (const WfRec*)c->d_wf_recs; c->wf_recs.ms_time0 = t0; c->wf_recs.ms_time1 = t1;
-        }
-    }
+    /* the opt-in modes' own data (f32 scene arrays, the wavefront form's walk records) are built at their first use:
+     * ensure_f32_scene / ensure_wf_recs */
+    c->h_nodes = s->flat_nodes; c->h_lights = s->flat_lights; c->h_materials = s->materials; c->h_textures = s->textures; c->h_perlin = s->perlin;
     if (rt1w::jit_eligible(*s)) {
         c->jit_src = rt1w::jit_source(*s);
         c->jit32_src = rt1w::jit_source(*s, true);
@@ -744,6 +784,7 @@ int rt1w_context_specialise(rt1w_context* c, uint32_t flags, rt1w_specialise_inf
     rt1w::JitInfo info;
     const bool had = c->jit_fn != nullptr;
     int rc = specialise(c, !(flags & RT1W_SPECIALISE_CACHED_ONLY), info);
+    if (rc == RT1W_OK && c->jit_fn) (void)specialise_f32(c, !(flags & RT1W_SPECIALISE_CACHED_ONLY)); /* optional: a failure leaves f32 renders on the generic kernels */
     if (out) {
         memset(out, 0, sizeof *out);
         snprintf(out->key, sizeof out->key, "%s", c->jit_key.c_str());

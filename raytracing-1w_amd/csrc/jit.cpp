@@ -53,7 +53,8 @@ bool load_hiprtc(std::string& err) {
     if (g_rtc.tried) { if (!g_rtc.ok) err = "libhiprtc.so is not available"; return g_rtc.ok; }
     g_rtc.tried = true;
     const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
-    for (const char* n : names) { g_rtc.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rtc.lib) break; }
+    if (!std::getenv("RT1W_NO_HIPRTC")) /* tests: a host without the run-time compiler */
+        for (const char* n : names) { g_rtc.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rtc.lib) break; }
     if (!g_rtc.lib) { err = "libhiprtc.so is not available"; return false; }
 #define RT_SYM(field, name) *(void**)(&g_rtc.field) = dlsym(g_rtc.lib, name); if (!g_rtc.field) { err = std::string("libhiprtc.so lacks ") + name; return false; }
     RT_SYM(CreateProgram, "hiprtcCreateProgram")
@@ -92,7 +93,10 @@ std::vector<std::string> options() {
     return o;
 }
 
-/* the compiler's identity: a code object cached by another hiprtc / ROCm release must not be picked up */
+/* the compiler's identity.  It names the files of the USER cache (a code object another hiprtc / ROCm release left there is not
+ * picked up); it is NOT part of a kernel's key: the kernels under <libdir>/kernels were compiled by the build's toolchain for
+ * this very library (same source, headers, options = same key) and are valid whatever hiprtc the host has, or none -- a code
+ * object the driver refuses is simply skipped (hipModuleLoadData fails, the generic kernels run). */
 std::string compiler_id() {
     std::string err;
     if (!load_hiprtc(err)) return "hiprtc-absent";
@@ -137,6 +141,11 @@ std::string install_cache_dir() {
     std::string p = info.dli_fname;
     size_t k = p.rfind('/');
     return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/kernels";
+}
+std::string user_cache_tag() {
+    std::string id = compiler_id();
+    for (char& ch : id) if (!((ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'z') || ch == '.')) ch = '_';
+    return id;
 }
 /* RT1W_KERNEL_CACHE, or ~/.cache/rt1w: where kernels compiled at run time are kept */
 std::string user_cache_dir() {
@@ -183,7 +192,6 @@ std::string jit_key(const std::string& source) {
     h = fnv1a(h, source);
     for (int i = 0; i < RT_JIT_N_HEADERS; ++i) { h = fnv1a(h, rt_jit_header_names[i], std::strlen(rt_jit_header_names[i])); h = fnv1a(h, rt_jit_header_texts[i], std::strlen(rt_jit_header_texts[i])); }
     for (const std::string& o : options()) h = fnv1a(h, o);
-    h = fnv1a(h, compiler_id());
     char buf[32];
     std::snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
     return buf;
@@ -227,21 +235,24 @@ int jit_get_code(const std::string& src, bool allow_compile, std::vector<char>& 
     info = JitInfo();
     if (src.empty()) { info.message = "scene is not eligible (more than RT_JIT_MAX_NODES nodes)"; return RT1W_ERR_UNSUPPORTED; }
     info.key = jit_key(src);
-    const std::string name = "/sweep_" + info.key + ".hsaco";
-    const std::string dirs[2] = {install_cache_dir(), user_cache_dir()};
-    for (const std::string& d : dirs) {
-        if (d.empty() || ignore_cache) continue;
-        if (read_file(d + name, code)) { info.from_cache = true; info.path = d + name; return RT1W_OK; }
+    /* 1. the installation's kernels (written by the build, rt1w_precompile): keyed by source + headers + options only */
+    const std::string inst = install_cache_dir();
+    if (!inst.empty() && !ignore_cache && read_file(inst + "/sweep_" + info.key + ".hsaco", code)) {
+        info.from_cache = true; info.path = inst + "/sweep_" + info.key + ".hsaco"; return RT1W_OK;
     }
+    /* 2. the user cache: files carry the compiler that made them (this is the first point that opens libhiprtc) */
+    const std::string user = user_cache_dir();
+    const std::string uname = "/sweep_" + info.key + "-" + user_cache_tag() + ".hsaco";
+    if (!user.empty() && !ignore_cache && read_file(user + uname, code)) { info.from_cache = true; info.path = user + uname; return RT1W_OK; }
     if (!allow_compile) { info.message = "no cached kernel for this topology"; return RT1W_ERR_STATE; }
     auto t0 = std::chrono::steady_clock::now();
     std::string log;
     int rc = jit_compile(src, code, log);
     info.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc < 0) { info.message = log; return rc; }
-    if (!dirs[1].empty()) {
-        mkdirs(dirs[1]);
-        if (write_file_atomic(dirs[1] + name, code)) info.path = dirs[1] + name;
+    if (!user.empty()) {
+        mkdirs(user);
+        if (write_file_atomic(user + uname, code)) info.path = user + uname;
     }
     return RT1W_OK;
 }
@@ -262,6 +273,9 @@ int jit_precompile_to(const rt1w_scene& s, const std::string& dir, JitInfo& info
     mkdirs(dir);
     if (!write_file_atomic(path, code)) { info.message = "cannot write " + path; return RT1W_ERR_STATE; }
     info.path = path;
+    /* which compiler made the directory's kernels: for the record only, no lookup reads it */
+    const std::string note = compiler_id() + "\n";
+    (void)write_file_atomic(dir + "/COMPILER", std::vector<char>(note.begin(), note.end()));
     return RT1W_OK;
 }
 

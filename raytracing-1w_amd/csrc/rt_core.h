@@ -463,10 +463,11 @@ RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
     bool hit;
     if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
     else hit = rt_aabb_hit_fast<EARLY>(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
-#if RT_BRANCHLESS_PUSH && defined(__HIP_DEVICE_COMPILE__) /* the CPU build keeps the pushes it can bound-check */
+#if RT_BRANCHLESS_PUSH /* the CPU test build runs the same form: its stack bound-checks every poke (oracle_flat.cpp) */
     if constexpr (!Cfg::ordered) {
-        /* both slots are written whatever the test said and the stack pointer moves by 0, 1 or 2: no nested exec-mask regions
-         * (a miss leaves two dead words above the top; the flattener's stack bound is the bound of the hit case) */
+        /* both slots are written whatever the test said and the stack pointer moves by 0, 1 or 2: no nested exec-mask regions.
+         * A miss, or a BVHChild::One, leaves dead words above the top: the flattener counts TWO slots for every BVH node
+         * (scene.cpp, Flattener::emit), so the footprint of the pokes is inside stack_need */
         const bool two = (nd.kind & RT_KIND_MASK) == RT_BVH2;
         stk.poke(0, two ? nd.b : e + 1u); /* BVH2: the right child below the left one (bvh.rs:38-47); BVH1: its only child */
         stk.poke(1, e + 1u);

@@ -251,7 +251,9 @@ struct Flattener {
                 uint32_t b = RT_NONE;
                 if (h.right >= 0) b = emit(h.right, parent_scope, scope_depth, in_boundary, &nb);
                 out[idx].a = a; out[idx].b = b;
-                *need = (h.right >= 0) ? std::max(2u, std::max(1u + na, nb)) : std::max(1u, na);
+                /* a BVHChild::One counts two slots like a Two: the walk writes both slots above the top whatever the node is
+                 * (rt_walk_box's branchless push) */
+                *need = (h.right >= 0) ? std::max(2u, std::max(1u + na, nb)) : std::max(2u, na);
                 return idx;
             }
             case RT_TRANSLATE: case RT_ROTATE_Y: case RT_FLIP: {
