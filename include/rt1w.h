@@ -321,6 +321,13 @@ int rt1w_debug_eval(rt1w_context* c, int fn, const double* a, const double* b, d
  * `out_literal` from the compare/select form, `out_fast` from the max/min-instruction form the kernels use when no
  * bound is NaN.  Tests compare both with the host's literal form. */
 int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* out_fast, uint64_t n);
+/* The shading-side leaf functions ON THE DEVICE for n inputs in[i] = {u, v, p.x, p.y, p.z}, out[i] = 3 doubles:
+ * mode 0 `Texture::value(u, v, p)` of texture `tex` of the context's scene (src/texture.rs:40-89) -> rgb;
+ * mode 1 `Perlin::noise(p)` and `Perlin::turb(p, 7)` of Perlin table `tex` (src/perlin.rs:46-86) -> out[0], out[1];
+ * mode 2 `sphere_uv(p)` (src/math.rs:67-71) -> out[0] = u, out[1] = v.
+ * Known-answer tests of what no artefact of the reference reaches (lattice points of the noise, checker parity, poles and
+ * seam of sphere_uv). */
+int rt1w_debug_texture(rt1w_context* c, int mode, uint32_t tex, const double* in, double* out, uint64_t n);
 /* per-phase wave-cycle totals of the render kernel since the last reset.  Only the diagnostic build
  * (make stamps -> librt1w_stamps.so, -DRT_STAMPS) fills them (returns 1); the shipped library executes no
  * stamp and returns 0 with zeros.  Buckets: see context.hip. */

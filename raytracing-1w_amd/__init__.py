@@ -143,6 +143,7 @@ _sig("rt1w_format_ppm", C.c_int64, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64)
 _sig("rt1w_debug_eval", C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64)
 _sig("rt1w_debug_aabb", C.c_int, _P, _P, _P, _P, C.c_uint64)
 _sig("rt1w_debug_stamps", C.c_int, _P, C.POINTER(C.c_uint64 * 16), C.c_int)
+_sig("rt1w_debug_texture", C.c_int, _P, C.c_int, C.c_uint32, _P, _P, C.c_uint64)
 
 
 for _i, _t in enumerate((RenderParams, Stats, SceneInfo, SpecialiseInfo)):
@@ -433,6 +434,14 @@ class Context:
         fast = np.empty(a.shape[0], dtype=np.int32)
         _ck(_lib.rt1w_debug_aabb(self._h, a.ctypes.data_as(_P), lit.ctypes.data_as(_P), fast.ctypes.data_as(_P), a.shape[0]))
         return lit, fast
+
+    def debug_texture(self, mode, tex, uvp):
+        """uvp[n, 5] = u, v, p.xyz -> out[n, 3] from the device: mode 0 Texture::value of texture `tex`, 1 Perlin noise / turb of
+        table `tex`, 2 sphere_uv(p) (rt1w_debug_texture)."""
+        a = np.ascontiguousarray(uvp, dtype=np.float64).reshape(-1, 5)
+        out = np.empty((a.shape[0], 3), dtype=np.float64)
+        _ck(_lib.rt1w_debug_texture(self._h, mode, tex, a.ctypes.data_as(_P), out.ctypes.data_as(_P), a.shape[0]))
+        return out
 
     def debug_stamps(self, reset=True):
         out = (C.c_uint64 * 16)()

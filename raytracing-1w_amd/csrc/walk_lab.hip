@@ -240,6 +240,23 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0q(RtSceneView sc, con
     }
 }
 
+/* ------------------------------------------------------------------------------------- texture probe -- */
+
+/* the shading-side leaf functions ON THE DEVICE, for known-answer tests of what no artefact of the reference pins:
+ * mode 0 Texture::value(u, v, p) of texture `tex` (texture.rs:40-89); mode 1 Perlin::noise(p) and Perlin::turb(p, 7) of
+ * Perlin table `tex` (perlin.rs:46-86); mode 2 sphere_uv(p) (math.rs:67-71).  in[i] = {u, v, p.x, p.y, p.z}. */
+__global__ void lab_texture_kernel(RtSceneView sc, int mode, uint32_t tex, const double* __restrict__ in, double* __restrict__ out, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u = in[i * 5], v = in[i * 5 + 1];
+    const RtV3 p = rt_v3(in[i * 5 + 2], in[i * 5 + 3], in[i * 5 + 4]);
+    RtV3 r = rt_v3(0.0, 0.0, 0.0);
+    if (mode == 0) r = rt_texture<RtCfgV1>(sc, tex, u, v, p);
+    else if (mode == 1) { r.x = rt_perlin_noise(sc.perlin[tex], p); r.y = rt_perlin_turb(sc.perlin[tex], p, 7); }
+    else { double uu, vv; rt_sphere_uv(p, uu, vv); r.x = uu; r.y = vv; }
+    out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
+}
+
 /* --------------------------------------------------------------------------------------- gather probe -- */
 
 /* What can the L1 deliver for the walk's access pattern?  Every lane reads `iters` 64-byte records of the node array at pseudo-random
@@ -814,6 +831,29 @@ int rt1w_lab_gather_probe(rt1w_lab* l, uint32_t iters, uint32_t blocks_per_cu, d
     }
     if (records_per_launch) *records_per_launch = (uint64_t)grid * 256ull * iters;
     return RT1W_OK;
+}
+
+int rt1w_debug_texture(rt1w_context* c, int mode, uint32_t tex, const double* in, double* out, uint64_t n) {
+    if (!c || !in || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (n == 0) return RT1W_OK;
+    RtSceneView view;
+    memcpy(&view, rt1w_internal_view(c), sizeof view);
+    if (mode < 0 || mode > 2) { rt1w::set_error("unknown mode"); return RT1W_ERR_INVALID; }
+    if (mode == 0 && tex >= view.n_textures) { rt1w::set_error("bad texture id"); return RT1W_ERR_INVALID; }
+    if (mode == 1 && view.perlin == nullptr) { rt1w::set_error("the scene has no Perlin table"); return RT1W_ERR_INVALID; }
+    if (!lab_ok(hipSetDevice(rt1w_internal_device(c)), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    double *din = nullptr, *dout = nullptr;
+    int rc = RT1W_OK;
+    if (!lab_ok(hipMalloc((void**)&din, n * 5 * sizeof(double)), "hipMalloc") || !lab_ok(hipMalloc((void**)&dout, n * 3 * sizeof(double)), "hipMalloc")) rc = RT1W_ERR_NOMEM;
+    if (rc == RT1W_OK) {
+        (void)hipMemcpy(din, in, n * 5 * sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(lab_texture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, view, mode, tex, din, dout, (unsigned long long)n);
+        if (!lab_ok(hipGetLastError(), "launch") || !lab_ok(hipDeviceSynchronize(), "texture probe kernel")) rc = RT1W_ERR_DEVICE;
+        else (void)hipMemcpy(out, dout, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    return rc;
 }
 
 int rt1w_lab_dump_rays(rt1w_lab* l, const rt1w_render_params* p, uint32_t n_bounces, double* out_host) {

@@ -36,8 +36,38 @@ def png_blocks_final():
     b = lin.reshape(8, 100, 8, 100, 3).mean(axis=(1, 3))
     sel = [(2, 0), (2, 1), (2, 2), (2, 3), (2, 5), (2, 6), (2, 7), (3, 0), (3, 1), (3, 2), (3, 3), (3, 6), (3, 7),
            (4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (4, 6), (4, 7)]
+    # Objects whose geometry and appearance are LITERALS of final_scene (no thread_rng, no Perlin table): the earth sphere
+    # (main.rs:747-753: centre (400,200,400), r 100, the image texture), the moving sphere (main.rs:693-707: (400,400,200) ->
+    # (430,400,200), r 50, lambertian (0.7,0.3,0.1)) and the blue subsurface ball (main.rs:715-733: glass sphere (360,150,145)
+    # r 70 filled with a density-0.2 medium).  Their projected discs (camera main.rs:931-934: from (478,278,-600) at (278,278,0),
+    # vfov 40, square) shrunk to 0.7 of the radius, the PNG's linear mean over each disc, and the PNG's own noise there:
+    # sigma_pixel = rms of (pixel - mean of its 3x3 neighbourhood) * sqrt(9/8), so sigma of the disc mean = sigma_pixel / sqrt(n).
+    look_from, look_at, vup = np.array([478.0, 278.0, -600.0]), np.array([278.0, 278.0, 0.0]), np.array([0.0, 1.0, 0.0])
+    w = (look_from - look_at) / np.linalg.norm(look_from - look_at)
+    u = np.cross(vup, w); u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    half = np.tan(np.radians(40.0) / 2.0)
+    discs = []
+    for name, centre, radius in (("earth sphere", (400.0, 200.0, 400.0), 100.0), ("moving sphere", (415.0, 400.0, 200.0), 50.0),
+                                 ("blue subsurface ball", (360.0, 150.0, 145.0), 70.0)):
+        d = np.array(centre) - look_from
+        depth = -np.dot(d, w)
+        cx = (0.5 + np.dot(d, u) / (2.0 * half * depth)) * 799.0
+        cy_up = (0.5 + np.dot(d, v) / (2.0 * half * depth)) * 799.0
+        rad = 0.7 * radius / (2.0 * half * depth) * 800.0 - (15.0 if name == "moving sphere" else 0.0) * 800.0 / (2.0 * half * depth)
+        cy = 799.0 - cy_up
+        yy, xx = np.mgrid[0:800, 0:800]
+        m = (xx - cx) ** 2 + (yy - cy) ** 2 <= rad ** 2
+        k = np.ones((3, 3)) / 9.0
+        loc = sum(np.roll(np.roll(lin, dy, 0), dx, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)) / 9.0
+        resid = (lin - loc)[m]
+        sigma_pixel = np.sqrt((resid ** 2).mean(axis=0) * 9.0 / 8.0)
+        discs.append({"name": name, "cx": float(cx), "cy_top_down": float(cy), "radius_px": float(rad), "pixels": int(m.sum()),
+                      "png_linear_mean": lin[m].mean(axis=0).tolist(), "png_sigma_of_mean": (sigma_pixel / np.sqrt(m.sum())).tolist(),
+                      "saturated_fraction": float((im[m] >= 255).any(axis=1).mean())})
     return {"source": "next_week.png (hatoo/raytracing-1w, README.md:15; rendered by an earlier revision, see make_golden.py)",
-            "shape": [800, 800], "block": 100, "linear_block_means_top_down": b.tolist(), "selected_blocks": sel}
+            "shape": [800, 800], "block": 100, "linear_block_means_top_down": b.tolist(), "selected_blocks": sel,
+            "literal_object_discs": discs}
 
 def png_pixels():
     """Pixel-level pin: rest_of_your_life.png IS what `cargo run` of master prints (Cornell arm, 600x600, 100 spp,

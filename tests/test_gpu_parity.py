@@ -579,7 +579,7 @@ def test_c4_full_size_800x800_10000spp(rt, gpu_ctx_factory):
     """BASELINE C4 at FULL size on one GPU (6.4e9 paths): the whole frame at the reference's own 10 000 spp
     (main.rs:917-919) against next_week.png on its comparable blocks, tighter than the 200-spp test, + a crop against
     the CPU core build."""
-    from test_golden import final_png_block_check
+    from test_golden import final_png_block_check, final_png_disc_check
     sc = rt.Scene.reference(7, build_seed=1)
     ctx = gpu_ctx_factory(sc)
     W = H = 800
@@ -587,6 +587,7 @@ def test_c4_full_size_800x800_10000spp(rt, gpu_ctx_factory):
     full, st = ctx.render_rows(W, H, spp)
     assert st["paths"] == W * H * spp
     final_png_block_check(full, 0.11, 0.02)
+    final_png_disc_check(full, 0.08, "C4 full size: ")     # the literal objects (earth, moving sphere, blue ball): tighter than the blocks
     tile = (392, 300, 4, 2)
     b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=rt.default_chunk(W, H, spp))
     assert np.array_equal(full[300:302, 392:396], b, equal_nan=True)

@@ -15,13 +15,13 @@ for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   (cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/p$i -- python3 tools/walk_lab.py "$@" > $OUT/p$i.log 2>&1) || echo "pass $i failed"
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        k = "lab_trace_w0q" if "lab_trace_w0q" in k else "lab_trace_w0" if "lab_trace_w0" in k else ("lab_trace_w1<" + ",".join("1" if x == "Lb1" else "0" for x in __import__("re").findall(r"Lb[01]", k)[:2]) + ">" if "lab_trace_w1" in k else None)
+        m = re.search(r"lab_trace_(w0q|w0|w2|w1<[^>]*>)", r["Kernel_Name"])
+        k = ("lab_trace_" + m.group(1).replace(" ", "")) if m else None
         if k:
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 with open("$OUT/summary.txt", "w") as o:

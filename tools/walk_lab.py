@@ -93,7 +93,7 @@ def main():
     sets = []
     for b in range(bounces):
         v = rays[b][rays[b][:, 7] != 0.0]
-        if len(v) > 1000000:     # a persistent grid holds ~200 k lanes: smaller sets measure the tail, not the walk
+        if len(v) > 1000000 and "--all-only" not in sys.argv:     # a persistent grid holds ~200 k lanes: smaller sets measure the tail, not the walk
             sets.append((f"bounce {b}", v))
     # the mix a render holds: every path's rays one after the other (path-major), i.e. neighbouring lanes hold different bounces
     pm = np.transpose(rays, (1, 0, 2)).reshape(-1, 8)
