@@ -238,6 +238,7 @@ def stored_pmc(workload, kernel, spec_key):
         return None
     same = ent.get("kernel") == kernel and (ent.get("specialise_key") in (None, spec_key))
     ent = dict(ent, matches_this_run=bool(same), file="profiles/pmc_summary.json")
+    ent.pop("kernel_names_seen", None)
     return ent
 
 
@@ -248,7 +249,7 @@ def kernel_name(st):
     return ("rt_render_kernel_sorted<V%d>" if (flags & 1) else "rt_render_kernel<V%d>") % st["variant"]
 
 
-def roofline_block(workload, st, kernel_ms, pixels, spec_key):
+def roofline_block(workload, st, kernel_ms, pixels, spec_key, spp=None):
     """roofline of the dominant kernel: algorithmic bytes per launch = 2 * 128 B per traced segment (ray-state record read +
     written once per segment) + 24 B per pixel; duration from HIP events on the kernel's own stream"""
     segs = st["segments"]
@@ -259,7 +260,7 @@ def roofline_block(workload, st, kernel_ms, pixels, spec_key):
     ok = bool(pmc and pmc["matches_this_run"])
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": pmc.get("hbm_bytes_per_launch") if ok else None,
+            "traffic": pmc.get("hbm_bytes_per_launch") if (ok and spp == pmc.get("spp_of_the_traffic_figure")) else None,
             "valu_lane_issue_frac": pmc.get("valu_lane_issue_frac") if ok else None,
             "pmc_source": pmc,
             "kernel": kernel, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
@@ -300,7 +301,8 @@ def measure_single(be, dev, key, spp, steps, warmup, bvh, walk_order, generic=Fa
            "value_kernel_only": round(paths / kernel_ms / 1e3, 2),
            "paths_per_step": paths, "segments_per_path": round(st["segments"] / paths, 4),
            "scene_nodes": scene.info()["n_nodes"], "bvh": bvh_label(bvh, walk_order), "dtype": "f64",
-           "roofline": roofline_block(key, st, kernel_ms, W * H, spec.get("key") if spec else None)}
+           "roofline": roofline_block(key if (bvh == "reference" and walk_order == "reference") else None, st, kernel_ms, W * H,
+                                      spec.get("key") if spec else None, spp)}
     ctx.close()
     return out
 
@@ -460,8 +462,8 @@ def rank_main(a, be=None):
                            "host_frame_pin_error": getattr(frame, "pin_error", None) if frame is not None else None,
                            "backend": be.name, "commit": git_head()},
                 "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
-                "roofline": roofline_block(a.workload if (spp == wl["spp"] and world == 1) else None, st, avg_ms, my_pixels,
-                                           spec.get("key") if spec else None),
+                "roofline": roofline_block(a.workload if (world == 1 and a.bvh == "reference" and a.walk_order == "reference") else None, st, avg_ms,
+                                           my_pixels, spec.get("key") if spec else None, spp),
             }
             if frame_check is not None:
                 line["gathered_frame_equals_single_gpu_frame"] = frame_check

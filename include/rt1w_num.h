@@ -60,6 +60,9 @@ RT_HD uint64_t rt_d2u(rt_f64 x) { uint64_t u; __builtin_memcpy(&u, &x, 8); retur
 RT_HD rt_f64 rt_u2d(uint64_t u) { rt_f64 x; __builtin_memcpy(&x, &u, 8); return x; }
 
 #define RT_INF (__builtin_huge_val())
+/* a constant in the working precision of the build: `double` itself in the f64 builds (a no-op), float where the f32 build
+ * redefines the keyword (csrc/context_f32.hip) -- there an untyped literal would drag the expression around it into f64 */
+#define RT_R(x) ((double)(x))
 #define RT_PI 3.14159265358979323846264338327950288
 
 RT_HD bool rt_isnan(double x) { return x != x; }
@@ -500,8 +503,20 @@ RT_HD rt_f64 rt_log(rt_f64 x) {
 RT_HD double rt_pow5(double x) { double x2 = x * x; return (x2 * x2) * x; }
 
 #if defined(RT_F32)
-/* f32 build: the callers hold floats; the functions above run in 64 bits and the result is rounded once */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_F32_ELEMENTARY_F64)
+/* device f32 build: the elementary functions of a float argument in single precision (the compiler's own: ~1-2 ulp of f32).
+ * This mode's parity with the reference is statistical (tests/test_gpu_parity.py::test_f32_mode_*), not bitwise, and the
+ * 64-bit evaluations were half of the feature-rich f32 kernels' instructions. */
+RT_HD double rt_sin(double x) { return ::sinf(x); }
+RT_HD double rt_cos(double x) { return ::cosf(x); }
+RT_HD void rt_sincos(double x, double& s, double& c) { s = ::sinf(x); c = ::cosf(x); }
+RT_HD double rt_atan2(double y, double x) { return ::atan2f(y, x); }
+RT_HD double rt_acos(double x) { return ::acosf(x); }
+RT_HD double rt_log(double x) { return ::logf(x); }
+#else
+/* f32 build on the host (and with RT_F32_ELEMENTARY_F64): the functions above run in 64 bits and the result is rounded once */
 RT_HD void rt_sincos(double x, double& s, double& c) { rt_f64 s64, c64; rt_sincos((rt_f64)x, s64, c64); s = (double)s64; c = (double)c64; }
+#endif
 #endif
 
 /* ------------------------------------------------------------------ vec3 -- */

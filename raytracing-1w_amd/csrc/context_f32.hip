@@ -37,12 +37,16 @@ namespace rtf32 {
 #include "rt_kernel_sorted.h"
 #include "rt_kernel_plain.h"
 
+/* waves per SIMD the f32 kernels are built for.  The Cornell variant V0 fits 4 (127 VGPRs, no spill).  The feature-rich variants do
+ * not: held to 128 registers they spill 140-200 of them (and the reordering kernels missed the bound anyway: 3 and 2 waves), so
+ * they are built for 3 like their f64 forms (measured: profiles/r03_f32_occupancy.txt). */
+#define RT_F32_WAVES(Cfg) ((Cfg::sweep && !Cfg::media && !Cfg::tex && !Cfg::msphere) ? 4 : 3)
 template <class Cfg>
-__global__ __launch_bounds__(RT_BLOCK, 4) void rt_render_kernel_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(RT_BLOCK, RT_F32_WAVES(Cfg)) void rt_render_kernel_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
     rt_render_plain_body<Cfg, false>(sc, f, partial, counters);
 }
 template <class Cfg>
-__global__ __launch_bounds__(RT_SORT_BLOCK, 4) void rt_render_kernel_sorted_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_sorted_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
     rt_render_sorted_body<Cfg>(sc, f, partial, counters);
 }
 typedef void (*kernel_t)(RtSceneView, RtFrame, rt_f64*, unsigned long long*);

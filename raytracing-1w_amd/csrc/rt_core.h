@@ -83,7 +83,7 @@ RT_HD bool rt_aabb_hit(const double* bb, RtV3 o, RtV3 inv, double t_min, double 
     {                                                    \
         double t0 = ((minv) - (ov)) * (iv);              \
         double t1 = ((maxv) - (ov)) * (iv);              \
-        if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
+        if ((iv) < RT_R(0.0)) { double s_ = t0; t0 = t1; t1 = s_; } \
         t_min = t0 > t_min ? t0 : t_min;                 \
         t_max = t1 < t_max ? t1 : t_max;                 \
         if (t_max <= t_min) return false;                \
@@ -124,7 +124,7 @@ RT_HD bool rt_aabb_hit_fast(const double* bb, RtV3 o, RtV3 inv, double t_min, do
     {                                                    \
         double t0 = ((minv) - (ov)) * (iv);              \
         double t1 = ((maxv) - (ov)) * (iv);              \
-        if ((iv) < 0.0) { double s_ = t0; t0 = t1; t1 = s_; } \
+        if ((iv) < RT_R(0.0)) { double s_ = t0; t0 = t1; t1 = s_; } \
         t_min = rt_vmax(t0, t_min);                      \
         t_max = rt_vmin(t1, t_max);                      \
         if (EARLY) { if (t_max <= t_min) return false; } \
@@ -145,7 +145,7 @@ RT_HD bool rt_sphere_root(RtV3 center, double radius, RtV3 o, RtV3 d, double t_m
     double half_b = rt_dot(oc, d);
     double c = rt_mag2(oc) - radius * radius;
     double discriminant = half_b * half_b - a * c;
-    if (discriminant < 0.0) return false;
+    if (discriminant < RT_R(0.0)) return false;
     double sqrtd = rt_sqrt(discriminant);
     double root = (-half_b - sqrtd) / a;
     if (root < t_min || t_max < root) {
@@ -213,7 +213,7 @@ RT_HD RtRayOD rt_scope_in(const NodeT& s, RtRayOD r) {
 RT_HD void rt_scope_out(const RtNode& s, RtRayOD inner, RtHit& h) {
     if (s.kind == RT_TRANSLATE) {
         h.p = h.p + rt_v3(s.d[0], s.d[1], s.d[2]);
-        bool front = rt_dot(inner.d, h.n) < 0.0;
+        bool front = rt_dot(inner.d, h.n) < RT_R(0.0);
         h.n = front ? h.n : -h.n;
         h.front = front;
     } else if (s.kind == RT_ROTATE_Y) {
@@ -223,7 +223,7 @@ RT_HD void rt_scope_out(const RtNode& s, RtRayOD inner, RtHit& h) {
         p.z = -sn * h.p.x + cs * h.p.z;
         n.x = cs * h.n.x + sn * h.n.z;
         n.z = -sn * h.n.x + cs * h.n.z;
-        bool front = rt_dot(inner.d, n) < 0.0;
+        bool front = rt_dot(inner.d, n) < RT_R(0.0);
         h.p = p;
         h.n = front ? n : -n;
         h.front = front;
@@ -265,9 +265,9 @@ RT_HD RtRayOD rt_ray_in_scope_r(const RtNode* nodes, uint32_t scope, RtRayOD wor
 /* sphere_uv math.rs:67-71 */
 RT_HD void rt_sphere_uv(RtV3 p, double& u, double& v) {
     double theta = rt_acos(-p.y);
-    double phi = rt_atan2(-p.z, p.x) + RT_PI;
-    u = phi / (2.0 * RT_PI);
-    v = theta / RT_PI;
+    double phi = rt_atan2(-p.z, p.x) + RT_R(RT_PI);
+    u = phi / (RT_R(2.0) * RT_R(RT_PI));
+    v = theta / RT_R(RT_PI);
 }
 
 /* The leaf's own HitRecord (sphere.rs:50-62, moving_sphere.rs:57-69, aarect.rs:58-71,
@@ -277,7 +277,7 @@ RT_HD void rt_sphere_uv(RtV3 p, double& u, double& v) {
 template <class Cfg>
 RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bool want_uv,
                           RtHit& h) {
-    h.t = t; h.u = 0.0; h.v = 0.0; h.mat = nd.mat;
+    h.t = t; h.u = RT_R(0.0); h.v = RT_R(0.0); h.mat = nd.mat;
     h.p = rt_at(r.o, r.d, t);
     RtV3 on;
     const uint32_t kind = nd.kind & RT_KIND_MASK;
@@ -287,21 +287,21 @@ RT_HD void rt_leaf_record(const RtNode& nd, RtRayOD r, double time, double t, bo
         else on = (h.p - rt_msphere_center(nd, time)) / nd.e[2];
         if (Cfg::tex && want_uv) rt_sphere_uv(on, h.u, h.v);
     } else if (Cfg::media && kind == RT_MEDIUM) {
-        h.n = rt_v3(1.0, 0.0, 0.0);
+        h.n = rt_v3(RT_R(1.0), RT_R(0.0), RT_R(0.0));
         h.front = true;
         return;
     } else {
         double b, c;
-        if (kind == RT_XY) { on = rt_v3(0.0, 0.0, 1.0); b = r.o.x + t * r.d.x; c = r.o.y + t * r.d.y; }
-        else if (kind == RT_XZ) { on = rt_v3(0.0, 1.0, 0.0); b = r.o.x + t * r.d.x; c = r.o.z + t * r.d.z; }
-        else { on = rt_v3(1.0, 0.0, 0.0); b = r.o.y + t * r.d.y; c = r.o.z + t * r.d.z; }
+        if (kind == RT_XY) { on = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(1.0)); b = r.o.x + t * r.d.x; c = r.o.y + t * r.d.y; }
+        else if (kind == RT_XZ) { on = rt_v3(RT_R(0.0), RT_R(1.0), RT_R(0.0)); b = r.o.x + t * r.d.x; c = r.o.z + t * r.d.z; }
+        else { on = rt_v3(RT_R(1.0), RT_R(0.0), RT_R(0.0)); b = r.o.y + t * r.d.y; c = r.o.z + t * r.d.z; }
         if (Cfg::tex && want_uv) {
             h.u = (b - nd.d[0]) / (nd.d[1] - nd.d[0]);
             h.v = (c - nd.d[2]) / (nd.d[3] - nd.d[2]);
         }
     }
     /* HitRecord::new hittable.rs:30-35 */
-    bool front = rt_dot(r.d, on) < 0.0;
+    bool front = rt_dot(r.d, on) < RT_R(0.0);
     h.n = front ? on : -on;
     h.front = flipped ? !front : front; /* FlipFace::hit hittable.rs:288-291 flips the flag only */
 }
@@ -377,7 +377,7 @@ struct RtGlobalNodes {
 
 /* ----------------------------------------------------------- traversal -- */
 
-RT_HD RtV3 rt_inv3(RtV3 d) { return rt_v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+RT_HD RtV3 rt_inv3(RtV3 d) { return rt_v3(RT_R(1.0) / d.x, RT_R(1.0) / d.y, RT_R(1.0) / d.z); }
 
 /* ConstantMedium::hit constant_medium.rs:58-113, given the two boundary roots t1, t2 */
 RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_min, double t_max, RtRng& rng,
@@ -385,7 +385,7 @@ RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_
     double rec1 = rt_max(t1, t_min);
     double rec2 = rt_min(t2, t_max);
     if (rec1 >= rec2) return false;
-    rec1 = rt_max(rec1, 0.0);
+    rec1 = rt_max(rec1, RT_R(0.0));
     double ray_length = rt_mag(d);
     double distance_inside_boundary = (rec2 - rec1) * ray_length;
     rt_rng_reserve(rng, rt_rng_need_u64(rng));
@@ -482,7 +482,7 @@ RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
             if (Cfg::ordered && ord != 0u) { /* opt-in near-far order (variant V4 only): the child on the ray's near side first */
                 const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
                 const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
-                if ((da < 0.0 && left_lower) || (da > 0.0 && !left_lower)) { first = nd.b; second = e + 1u; }
+                if ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower)) { first = nd.b; second = e + 1u; }
             }
             stk.push(second);
             stk.push(first);
@@ -529,10 +529,10 @@ RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_
             /* the boundary is a bare Sphere (every medium of the reference's scenes): its walk is one stack entry, one leaf
              * test -- run the two tests (sphere.rs:31-48 with (-inf, inf), then (t1 + 0.0001, inf)) without the walk around them */
             const RtV3 c = rt_v3(bn.d[0], bn.d[1], bn.d[2]);
-            both = rt_sphere_root(c, bn.d[3], br.o, br.d, -RT_INF, RT_INF, t1) && rt_sphere_root(c, bn.d[3], br.o, br.d, t1 + 0.0001, RT_INF, t2);
+            both = rt_sphere_root(c, bn.d[3], br.o, br.d, -RT_INF, RT_INF, t1) && rt_sphere_root(c, bn.d[3], br.o, br.d, t1 + RT_R(0.0001), RT_INF, t2);
         } else {
             both = rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_, &k.inv) &&
-                   rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + 0.0001, RT_INF, rng, stk, t2, p_, s_, &k.inv);
+                   rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + RT_R(0.0001), RT_INF, rng, stk, t2, p_, s_, &k.inv);
         }
         if (both && rt_medium_t(sc.nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
             k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
@@ -640,7 +640,7 @@ RT_HD void rt_walk_push_children(RtWalk& k, uint32_t e, const RtNodeHot& nd, Sta
         if (Cfg::ordered && ord != 0u) {
             const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
             const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
-            if ((da < 0.0 && left_lower) || (da > 0.0 && !left_lower)) { first = nd.b; second = e + 1u; }
+            if ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower)) { first = nd.b; second = e + 1u; }
         }
         stk.push(second);
     }
@@ -790,7 +790,7 @@ RT_HD bool rt_traverse_sweep(const RtSceneView& sc, const NS& ns, uint32_t root,
                     RtRay br; br.o = cur_ray.o; br.d = cur_ray.d; br.time = world.time;
                     double t1, t2, t; uint32_t p_, s_;
                     if (rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, -RT_INF, RT_INF, rng, t1, p_, s_) &&
-                        rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, t1 + 0.0001, RT_INF, rng, t2, p_, s_) &&
+                        rt_traverse_sweep<Cfg, false>(sc, ns, n + 1u, br, t1 + RT_R(0.0001), RT_INF, rng, t2, p_, s_) &&
                         rt_medium_t(full, cur_ray.d, t1, t2, t_min, best_t, rng, t)) {
                         best_t = t; best_prim = n; best_scope = scope;
                     }
@@ -867,7 +867,7 @@ RT_HD void rt_sweep_static(const RtSceneView& sc, const NS& ns, const RtRayOD& r
                         uint32_t c1 = I + 1u, p1 = RT_NONE, c2 = I + 1u, p2 = RT_NONE;
                         rt_sweep_static<Topo, Cfg, false, I + 1u, skip>(sc, ns, ray, inv, time, -RT_INF, false, rng, c1, t1, p1);
                         if (p1 != RT_NONE) {
-                            const double lo = t1 + 0.0001;
+                            const double lo = t1 + RT_R(0.0001);
                             rt_sweep_static<Topo, Cfg, false, I + 1u, skip>(sc, ns, ray, inv, time, lo, rt_isnan(lo), rng, c2, t2, p2);
                             if (p2 != RT_NONE && rt_medium_t(full, ray.d, t1, t2, t_min, best_t, rng, t)) { best_t = t; best_prim = I; }
                         }
@@ -904,13 +904,13 @@ RT_HD double rt_perlin_noise(const RtPerlin& pl, RtV3 p) {
     double fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
     double u = p.x - fx, v = p.y - fy, w = p.z - fz;
     /* `as isize` saturates; & 255 afterwards */
-    int64_t i = (fx >= 9.2e18) ? INT64_MAX : (fx <= -9.2e18) ? INT64_MIN : (fx != fx ? 0 : (int64_t)fx);
-    int64_t j = (fy >= 9.2e18) ? INT64_MAX : (fy <= -9.2e18) ? INT64_MIN : (fy != fy ? 0 : (int64_t)fy);
-    int64_t k = (fz >= 9.2e18) ? INT64_MAX : (fz <= -9.2e18) ? INT64_MIN : (fz != fz ? 0 : (int64_t)fz);
-    double uu = u * u * (3.0 - 2.0 * u);
-    double vv = v * v * (3.0 - 2.0 * v);
-    double ww = w * w * (3.0 - 2.0 * w);
-    double accum = 0.0;
+    int64_t i = (fx >= RT_R(9.2e18)) ? INT64_MAX : (fx <= -RT_R(9.2e18)) ? INT64_MIN : (fx != fx ? 0 : (int64_t)fx);
+    int64_t j = (fy >= RT_R(9.2e18)) ? INT64_MAX : (fy <= -RT_R(9.2e18)) ? INT64_MIN : (fy != fy ? 0 : (int64_t)fy);
+    int64_t k = (fz >= RT_R(9.2e18)) ? INT64_MAX : (fz <= -RT_R(9.2e18)) ? INT64_MIN : (fz != fz ? 0 : (int64_t)fz);
+    double uu = u * u * (RT_R(3.0) - RT_R(2.0) * u);
+    double vv = v * v * (RT_R(3.0) - RT_R(2.0) * v);
+    double ww = w * w * (RT_R(3.0) - RT_R(2.0) * w);
+    double accum = RT_R(0.0);
     for (int di = 0; di < 2; ++di)
         for (int dj = 0; dj < 2; ++dj)
             for (int dk = 0; dk < 2; ++dk) {
@@ -922,26 +922,26 @@ RT_HD double rt_perlin_noise(const RtPerlin& pl, RtV3 p) {
                 RtV3 c = rt_v3(pl.ranvec[idx * 3 + 0], pl.ranvec[idx * 3 + 1], pl.ranvec[idx * 3 + 2]);
                 double fi = (double)di, fj = (double)dj, fk = (double)dk;
                 RtV3 weight_v = rt_v3(u - fi, v - fj, w - fk);
-                accum += (fi * uu + (1.0 - fi) * (1.0 - uu)) * (fj * vv + (1.0 - fj) * (1.0 - vv)) *
-                         (fk * ww + (1.0 - fk) * (1.0 - ww)) * rt_dot(c, weight_v);
+                accum += (fi * uu + (RT_R(1.0) - fi) * (RT_R(1.0) - uu)) * (fj * vv + (RT_R(1.0) - fj) * (RT_R(1.0) - vv)) *
+                         (fk * ww + (RT_R(1.0) - fk) * (RT_R(1.0) - ww)) * rt_dot(c, weight_v);
             }
     return accum;
 }
 /* Perlin::turb perlin.rs:74-86 */
 RT_HD double rt_perlin_turb(const RtPerlin& pl, RtV3 p, int depth) {
-    double accum = 0.0, weight = 1.0;
+    double accum = RT_R(0.0), weight = RT_R(1.0);
     RtV3 temp_p = p;
     for (int i = 0; i < depth; ++i) {
         accum += weight * rt_perlin_noise(pl, temp_p);
-        weight *= 0.5;
-        temp_p = temp_p * 2.0;
+        weight *= RT_R(0.5);
+        temp_p = temp_p * RT_R(2.0);
     }
     return rt_abs(accum);
 }
 /* `x as u32` of Rust: saturating, NaN -> 0 */
 RT_HD uint32_t rt_as_u32(double x) {
-    if (!(x > 0.0)) return 0u;
-    if (x >= 4294967295.0) return 4294967295u;
+    if (!(x > RT_R(0.0))) return 0u;
+    if (x >= RT_R(4294967295.0)) return 4294967295u;
     return (uint32_t)x;
 }
 /* Texture::value texture.rs:40-89 */
@@ -954,24 +954,24 @@ RT_HD RtV3 rt_texture(const RtSceneView& sc, uint32_t tex, double u, double v, R
     for (;;) {
         const RtTexture& t = sc.textures[tex];
         if (t.kind == RT_TEX_CHECKER) {
-            double sines = rt_sin(10.0 * p.x) * rt_sin(10.0 * p.y) * rt_sin(10.0 * p.z);
-            tex = (sines < 0.0) ? t.a : t.b;
+            double sines = rt_sin(RT_R(10.0) * p.x) * rt_sin(RT_R(10.0) * p.y) * rt_sin(RT_R(10.0) * p.z);
+            tex = (sines < RT_R(0.0)) ? t.a : t.b;
             continue;
         }
         if (t.kind == RT_TEX_SOLID) return rt_v3(t.d[0], t.d[1], t.d[2]);
         if (t.kind == RT_TEX_NOISE) {
-            double s = 1.0 * 0.5 * (1.0 + rt_sin(t.d[0] * p.z + 10.0 * rt_perlin_turb(sc.perlin[t.a], p, 7)));
+            double s = RT_R(1.0) * RT_R(0.5) * (RT_R(1.0) + rt_sin(t.d[0] * p.z + RT_R(10.0) * rt_perlin_turb(sc.perlin[t.a], p, 7)));
             return rt_v3(s, s, s);
         }
         /* RT_TEX_IMAGE texture.rs:67-88 */
-        double uc = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
-        double vc = 1.0 - (v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v));
+        double uc = u < RT_R(0.0) ? RT_R(0.0) : (u > RT_R(1.0) ? RT_R(1.0) : u);
+        double vc = RT_R(1.0) - (v < RT_R(0.0) ? RT_R(0.0) : (v > RT_R(1.0) ? RT_R(1.0) : v));
         uint32_t i = rt_as_u32(uc * (double)t.a);
         uint32_t j = rt_as_u32(vc * (double)t.b);
         i = i < t.a - 1u ? i : t.a - 1u;
         j = j < t.b - 1u ? j : t.b - 1u;
         const uint8_t* px = sc.images + t.c + ((size_t)j * t.a + i) * 3u;
-        const double COLOR_SCALE = 1.0 / 255.0;
+        const double COLOR_SCALE = RT_R(1.0) / RT_R(255.0);
         return rt_v3((double)px[0] * COLOR_SCALE, (double)px[1] * COLOR_SCALE, (double)px[2] * COLOR_SCALE);
     }
 }
@@ -989,30 +989,30 @@ RT_HD RtV3 rt_mat_colour(const RtSceneView& sc, const RtMaterial& m, double u, d
 RT_HD RtV3 rt_random_in_unit_sphere(RtRng& rng) {
     for (;;) {
         rt_rng_reserve(rng, rt_rng_need_2u64(rng));
-        double x = rt_take_range(rng, -1.0, 1.0);
-        double y = rt_take_range(rng, -1.0, 1.0);
+        double x = rt_take_range(rng, -RT_R(1.0), RT_R(1.0));
+        double y = rt_take_range(rng, -RT_R(1.0), RT_R(1.0));
         rt_rng_reserve(rng, rt_rng_need_u64(rng));
-        double z = rt_take_range(rng, -1.0, 1.0);
+        double z = rt_take_range(rng, -RT_R(1.0), RT_R(1.0));
         RtV3 v = rt_v3(x, y, z);
-        if (rt_mag2(v) < 1.0) return v;
+        if (rt_mag2(v) < RT_R(1.0)) return v;
     }
 }
 /* math.rs:30-37 */
 RT_HD RtV3 rt_random_in_unit_disk(RtRng& rng) {
     for (;;) {
         rt_rng_reserve(rng, rt_rng_need_2u64(rng));
-        double x = rt_take_range(rng, -1.0, 1.0);
-        double y = rt_take_range(rng, -1.0, 1.0);
-        RtV3 p = rt_v3(x, y, 0.0);
-        if (rt_mag2(p) < 1.0) return p;
+        double x = rt_take_range(rng, -RT_R(1.0), RT_R(1.0));
+        double y = rt_take_range(rng, -RT_R(1.0), RT_R(1.0));
+        RtV3 p = rt_v3(x, y, RT_R(0.0));
+        if (rt_mag2(p) < RT_R(1.0)) return p;
     }
 }
 /* math.rs:39-49 (caller has reserved two 64-bit draws) */
 RT_HD RtV3 rt_random_cosine_direction(RtRng& rng) {
     double r1 = rt_take_f64(rng);
     double r2 = rt_take_f64(rng);
-    double z = rt_sqrt(1.0 - r2);
-    double phi = 2.0 * RT_PI * r1;
+    double z = rt_sqrt(RT_R(1.0) - r2);
+    double phi = RT_R(2.0) * RT_R(RT_PI) * r1;
     double s, c;
     rt_sincos(phi, s, c);
     double sr2 = rt_sqrt(r2);
@@ -1022,11 +1022,11 @@ RT_HD RtV3 rt_random_cosine_direction(RtRng& rng) {
 RT_HD RtV3 rt_random_to_sphere(double radius, double distance_squared, RtRng& rng) {
     double r1 = rt_take_f64(rng);
     double r2 = rt_take_f64(rng);
-    double z = 1.0 + r2 * (rt_sqrt(1.0 - radius * radius / distance_squared) - 1.0);
-    double phi = 2.0 * RT_PI * r1;
+    double z = RT_R(1.0) + r2 * (rt_sqrt(RT_R(1.0) - radius * radius / distance_squared) - RT_R(1.0));
+    double phi = RT_R(2.0) * RT_R(RT_PI) * r1;
     double s, c;
     rt_sincos(phi, s, c);
-    double q = rt_sqrt(1.0 - z * z);
+    double q = rt_sqrt(RT_R(1.0) - z * z);
     return rt_v3(c * q, s * q, z);
 }
 
@@ -1035,7 +1035,7 @@ struct RtOnb { RtV3 u, v, w; };
 RT_HD RtOnb rt_onb_from_w(RtV3 n) {
     RtOnb o;
     o.w = rt_normalize(n);
-    RtV3 a = (rt_abs(o.w.x) > 0.9) ? rt_v3(0.0, 1.0, 0.0) : rt_v3(1.0, 0.0, 0.0);
+    RtV3 a = (rt_abs(o.w.x) > RT_R(0.9)) ? rt_v3(RT_R(0.0), RT_R(1.0), RT_R(0.0)) : rt_v3(RT_R(1.0), RT_R(0.0), RT_R(0.0));
     o.v = rt_normalize(rt_cross(o.w, a));
     o.u = rt_cross(o.w, o.v);
     return o;
@@ -1049,9 +1049,9 @@ RT_HD RtV3 rt_onb_local(const RtOnb& o, RtV3 a) { return o.u * a.x + o.v * a.y +
 RT_HD double rt_light_pdf_value(const RtNode& l, RtV3 o, RtV3 v) {
     if (l.kind == RT_XZ) {
         double t;
-        if (!rt_rect_t(l, o.y, v.y, o.x, v.x, o.z, v.z, 0.001, RT_INF, t)) return 0.0;
-        RtV3 on = rt_v3(0.0, 1.0, 0.0);
-        RtV3 normal = (rt_dot(v, on) < 0.0) ? on : -on;
+        if (!rt_rect_t(l, o.y, v.y, o.x, v.x, o.z, v.z, RT_R(0.001), RT_INF, t)) return RT_R(0.0);
+        RtV3 on = rt_v3(RT_R(0.0), RT_R(1.0), RT_R(0.0));
+        RtV3 normal = (rt_dot(v, on) < RT_R(0.0)) ? on : -on;
         double area = (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]);
         double distance_squared = t * t * rt_mag2(v);
         double cosine = rt_abs(rt_dot(v, normal) / rt_mag(v));
@@ -1060,12 +1060,12 @@ RT_HD double rt_light_pdf_value(const RtNode& l, RtV3 o, RtV3 v) {
     if (l.kind == RT_SPHERE) {
         double t;
         RtV3 center = rt_v3(l.d[0], l.d[1], l.d[2]);
-        if (!rt_sphere_root(center, l.d[3], o, v, 0.001, RT_INF, t)) return 0.0;
-        double cos_theta_max = rt_sqrt(1.0 - l.d[3] * l.d[3] / rt_mag2(center - o));
-        double solid_angle = 2.0 * RT_PI * (1.0 - cos_theta_max);
-        return 1.0 / solid_angle;
+        if (!rt_sphere_root(center, l.d[3], o, v, RT_R(0.001), RT_INF, t)) return RT_R(0.0);
+        double cos_theta_max = rt_sqrt(RT_R(1.0) - l.d[3] * l.d[3] / rt_mag2(center - o));
+        double solid_angle = RT_R(2.0) * RT_R(RT_PI) * (RT_R(1.0) - cos_theta_max);
+        return RT_R(1.0) / solid_angle;
     }
-    return 0.0;
+    return RT_R(0.0);
 }
 /* Hittable::random of one light: aarect.rs:140-147, sphere.rs:92-99, default (1,0,0)
  * (caller has reserved two 64-bit draws) */
@@ -1081,29 +1081,29 @@ RT_HD RtV3 rt_light_random(const RtNode& l, RtV3 o, RtRng& rng) {
         RtOnb uvw = rt_onb_from_w(direction);
         return rt_onb_local(uvw, rt_random_to_sphere(l.d[3], distance_squared, rng));
     }
-    return rt_v3(1.0, 0.0, 0.0);
+    return rt_v3(RT_R(1.0), RT_R(0.0), RT_R(0.0));
 }
 /* impl Hittable for [T]: pdf_value hittable.rs:144-150 */
 RT_HD double rt_lights_pdf_value(const RtSceneView& sc, RtV3 o, RtV3 v) {
-    double weight = 1.0 / (double)sc.n_lights;
-    double sum = 0.0;
+    double weight = RT_R(1.0) / (double)sc.n_lights;
+    double sum = RT_R(0.0);
     for (uint32_t i = 0; i < sc.n_lights; ++i) sum = sum + weight * rt_light_pdf_value(sc.lights[i], o, v);
     return sum;
 }
 
 /* ------------------------------------------------------------ materials -- */
 
-RT_HD RtV3 rt_reflect(RtV3 v, RtV3 n) { return v - 2.0 * rt_dot(v, n) * n; } /* material.rs:94-96 */
+RT_HD RtV3 rt_reflect(RtV3 v, RtV3 n) { return v - RT_R(2.0) * rt_dot(v, n) * n; } /* material.rs:94-96 */
 RT_HD RtV3 rt_refract(RtV3 uv, RtV3 n, double etai_over_etat) {               /* material.rs:114-119 */
-    double cos_theta = rt_min(rt_dot(-uv, n), 1.0);
+    double cos_theta = rt_min(rt_dot(-uv, n), RT_R(1.0));
     RtV3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
-    RtV3 r_out_parallel = -rt_sqrt(rt_abs(1.0 - rt_mag2(r_out_perp))) * n;
+    RtV3 r_out_parallel = -rt_sqrt(rt_abs(RT_R(1.0) - rt_mag2(r_out_perp))) * n;
     return r_out_perp + r_out_parallel;
 }
 RT_HD double rt_reflectance(double cosine, double ref_idx) {                  /* material.rs:121-125 */
-    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    double r0 = (RT_R(1.0) - ref_idx) / (RT_R(1.0) + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0 - r0) * rt_pow5(1.0 - cosine);
+    return r0 + (RT_R(1.0) - r0) * rt_pow5(RT_R(1.0) - cosine);
 }
 
 /* --------------------------------------------------------------- camera -- */
@@ -1128,8 +1128,8 @@ RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, ui
     p.ray.d = c.lower_left_corner + u * c.horizontal + v * c.vertical - c.origin - offset;
     rt_rng_reserve(p.rng, rt_rng_need_u64(p.rng));
     p.ray.time = rt_take_range(p.rng, c.time0, c.time1);
-    p.beta = rt_v3(1.0, 1.0, 1.0);
-    p.radiance = rt_v3(0.0, 0.0, 0.0);
+    p.beta = rt_v3(RT_R(1.0), RT_R(1.0), RT_R(1.0));
+    p.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
     p.depth_left = f.max_depth;
     p.alive = true;
 }
@@ -1156,9 +1156,9 @@ enum { RT_CLS_LAMBERT = 0, RT_CLS_DIELECTRIC = 1, RT_CLS_METAL = 2, RT_CLS_OTHER
 template <class Cfg, class Stack, class NS>
 RT_HD RtTrace rt_path_trace(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& stk) {
     RtTrace tr;
-    tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
+    tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
     if (p.depth_left == 0u) return tr;
-    bool found = rt_closest_hit<Cfg>(sc, ns, p.ray, 0.001, RT_INF, p.rng, stk, tr.t, tr.prim, tr.scope);
+    bool found = rt_closest_hit<Cfg>(sc, ns, p.ray, RT_R(0.001), RT_INF, p.rng, stk, tr.t, tr.prim, tr.scope);
     if (!found) { tr.prim = RT_NONE; return tr; }
     uint32_t mk = RT_MAT_KINDF(ns.hot(tr.prim).mat) & 0xFFu; /* the node carries its material's kind word */
     tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT
@@ -1176,7 +1176,7 @@ RT_HD RtTrace rt_path_trace(const RtSceneView& sc, const NS& ns, RtPath& p, Stac
 template <class Cfg>
 RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
     if (p.depth_left == 0u) {
-        p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
+        p.radiance = p.radiance + rt_mul(p.beta, rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0)));
         p.alive = false;
         return;
     }
@@ -1200,7 +1200,7 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
      * emitting material never scatters, so a path's radiance is beta (.) its
      * terminal value (light, background, or the zero of depth exhaustion). */
     if (mk == RT_MAT_DIFFUSE_LIGHT) {
-        RtV3 emitted = h.front ? rt_mat_colour<Cfg>(sc, m, h.u, h.v, h.p) : rt_v3(0.0, 0.0, 0.0);
+        RtV3 emitted = h.front ? rt_mat_colour<Cfg>(sc, m, h.u, h.v, h.p) : rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
         p.radiance = p.radiance + rt_mul(p.beta, emitted);
         p.alive = false; /* DiffuseLight::scatter -> None, main.rs:110-112 */
         return;
@@ -1243,7 +1243,7 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
             } else {
                 double r1 = rt_f64_from_bits(q1);
                 double r2 = rt_f64_from_bits(q2);
-                double phi = 2.0 * RT_PI * r1;
+                double phi = RT_R(2.0) * RT_R(RT_PI) * r1;
                 double sn, cs;
                 rt_sincos(phi, sn, cs);
                 if (lk == RT_SPHERE) {
@@ -1251,27 +1251,27 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
                     RtV3 direction = rt_v3(l.d[0], l.d[1], l.d[2]) - h.p;
                     double distance_squared = rt_mag2(direction);
                     RtOnb lw = rt_onb_from_w(direction);
-                    double z = 1.0 + r2 * (rt_sqrt(1.0 - l.d[3] * l.d[3] / distance_squared) - 1.0);
-                    double q = rt_sqrt(1.0 - z * z);
+                    double z = RT_R(1.0) + r2 * (rt_sqrt(RT_R(1.0) - l.d[3] * l.d[3] / distance_squared) - RT_R(1.0));
+                    double q = rt_sqrt(RT_R(1.0) - z * z);
                     dir = rt_onb_local(lw, rt_v3(cs * q, sn * q, z));
                 } else {
-                    double z = rt_sqrt(1.0 - r2);
+                    double z = rt_sqrt(RT_R(1.0) - r2);
                     double sr2 = rt_sqrt(r2);
                     dir = rt_onb_local(uvw, rt_v3(cs * sr2, sn * sr2, z));
                 }
             }
         } else {
-            dir = rt_v3(1.0, 0.0, 0.0); /* Hittable::random default, hittable.rs:69-71 */
+            dir = rt_v3(RT_R(1.0), RT_R(0.0), RT_R(0.0)); /* Hittable::random default, hittable.rs:69-71 */
         }
-        double p1 = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_PI, 0.0); /* CosinePdf::value pdf.rs:37-40 */
+        double p1 = rt_max(rt_dot(rt_normalize(dir), uvw.w) / RT_R(RT_PI), RT_R(0.0)); /* CosinePdf::value pdf.rs:37-40 */
         if (sc.n_lights > 0u) {
             double p0 = rt_lights_pdf_value(sc, h.p, dir);
-            pdf = 0.5 * p0 + 0.5 * p1; /* MixturePdf::value pdf.rs:58-60 */
+            pdf = RT_R(0.5) * p0 + RT_R(0.5) * p1; /* MixturePdf::value pdf.rs:58-60 */
         } else {
             pdf = p1;
         }
         /* Lambertian::scattering_pdf material.rs:82-91 */
-        double spdf = rt_max(rt_dot(h.n, rt_normalize(dir)) / RT_PI, 0.0);
+        double spdf = rt_max(rt_dot(h.n, rt_normalize(dir)) / RT_R(RT_PI), RT_R(0.0));
         p.beta = rt_mul(p.beta, attenuation * spdf) / pdf;
         p.ray.o = h.p; p.ray.d = dir;
         p.ray.time = h.t; /* main.rs:86: time = hit_record.t (reference quirk Q1) */
@@ -1284,17 +1284,17 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
         p.ray.o = h.p; p.ray.d = dir;
     } else if (mk == RT_MAT_DIELECTRIC) {
         /* Dielectric::scatter material.rs:133-160 */
-        double refraction_ratio = h.front ? 1.0 / m.d[0] : m.d[0];
+        double refraction_ratio = h.front ? RT_R(1.0) / m.d[0] : m.d[0];
         RtV3 unit_direction = rt_normalize(p.ray.d);
-        double cos_theta = rt_min(rt_dot(-unit_direction, h.n), 1.0);
-        double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
-        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        double cos_theta = rt_min(rt_dot(-unit_direction, h.n), RT_R(1.0));
+        double sin_theta = rt_sqrt(RT_R(1.0) - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > RT_R(1.0);
         RtV3 dir;
         if (cannot_refract || rt_reflectance(cos_theta, refraction_ratio) > rt_gen_f64(p.rng)) /* checked draw: rarely-run site */
             dir = rt_reflect(unit_direction, h.n);
         else
             dir = rt_refract(unit_direction, h.n, refraction_ratio);
-        p.beta = rt_mul(p.beta, rt_v3(1.0, 1.0, 1.0));
+        p.beta = rt_mul(p.beta, rt_v3(RT_R(1.0), RT_R(1.0), RT_R(1.0)));
         p.ray.o = h.p; p.ray.d = dir;
     } else if (Cfg::media && mk == RT_MAT_ISOTROPIC) {
         /* Isotropic::scatter constant_medium.rs:37-50 */
@@ -1304,7 +1304,7 @@ RT_HD void rt_path_shade(const RtSceneView& sc, RtPath& p, const RtTrace& tr) {
         p.ray.o = h.p; p.ray.d = dir;
     } else {
         /* impl Material for (): scatter -> None, emitted (0,0,0): main.rs:110-112 */
-        p.radiance = p.radiance + rt_mul(p.beta, rt_v3(0.0, 0.0, 0.0));
+        p.radiance = p.radiance + rt_mul(p.beta, rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0)));
         p.alive = false;
         return;
     }
@@ -1323,18 +1323,18 @@ RT_HD void rt_path_step(const RtSceneView& sc, const NS& ns, RtPath& p, Stack& s
 
 /* Color::into_sampled color.rs:14-21 */
 RT_HD RtV3 rt_into_sampled(RtV3 sum, uint32_t samples_per_pixel) {
-    double scale = 1.0 / (double)samples_per_pixel;
-    double r = rt_isnan(sum.x) ? 0.0 : sum.x;
-    double g = rt_isnan(sum.y) ? 0.0 : sum.y;
-    double b = rt_isnan(sum.z) ? 0.0 : sum.z;
+    double scale = RT_R(1.0) / (double)samples_per_pixel;
+    double r = rt_isnan(sum.x) ? RT_R(0.0) : sum.x;
+    double g = rt_isnan(sum.y) ? RT_R(0.0) : sum.y;
+    double b = rt_isnan(sum.z) ? RT_R(0.0) : sum.z;
     return rt_v3(r, g, b) * scale;
 }
 /* Display for SampledColor color.rs:56-65: (256 * sqrt(c).clamp(0, 0.999)) as usize */
 RT_HD uint32_t rt_quantize(double c) {
     double s = rt_sqrt(c);
-    if (s < 0.0) s = 0.0;
-    if (s > 0.999) s = 0.999;
-    double q = 256.0 * s;
+    if (s < RT_R(0.0)) s = RT_R(0.0);
+    if (s > RT_R(0.999)) s = RT_R(0.999);
+    double q = RT_R(256.0) * s;
     return (q != q) ? 0u : (uint32_t)q;
 }
 

@@ -73,7 +73,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
     bool fresh = true; /* `item` holds an id that was not decoded yet */
     bool have = false;
     uint32_t px = 0, py = 0, chunk = 0, s = 0, s_end = 0;
-    RtV3d sum = rt_v3d(0.0, 0.0, 0.0);
+    RtV3d sum = rt_v3d(RT_R(0.0), RT_R(0.0), RT_R(0.0));
     RtPath path;
     path.alive = false;
     unsigned long long segs = 0;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 if (px < f.tile_w && py < f.tile_h) {
                     s = chunk * f.chunk;
                     s_end = s + f.chunk < f.spp ? s + f.chunk : f.spp;
-                    sum = rt_v3d(0.0, 0.0, 0.0);
+                    sum = rt_v3d(RT_R(0.0), RT_R(0.0), RT_R(0.0));
                     have = true;
                 }
             }
@@ -131,12 +131,12 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 if (path.depth_left != 0u) { stk.push(sc.root); walking = true; }
             }
             RtTrace tr;
-            tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
+            tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
             if (walking) {
                 RtWalk k;
                 k.w.o = path.ray.o; k.w.d = path.ray.d;
                 k.inv_w = rt_inv3(k.w.d);
-                k.time = path.ray.time; k.t_min = 0.001; k.tmin_nan = false; k.base = 0;
+                k.time = path.ray.time; k.t_min = RT_R(0.001); k.tmin_nan = false; k.base = 0;
                 k.best_t = w_best_t; k.best_prim = w_best_prim; k.best_scope = w_best_scope; k.scope = w_scope;
                 if (Cfg::scope_depth == 0 || w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
                 else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }

@@ -83,12 +83,12 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
     unsigned long long item = (unsigned long long)blockIdx.x * RT_SORT_BLOCK + threadIdx.x;
     bool fresh = true, have = false, retired = false;
     uint32_t px = 0, py = 0, chunk = 0, s = 0;
-    RtV3d sum = rt_v3d(0.0, 0.0, 0.0);
+    RtV3d sum = rt_v3d(RT_R(0.0), RT_R(0.0), RT_R(0.0));
     RtPath path;
     path.alive = false;
     path.depth_left = 0u;
-    path.ray.o = path.ray.d = path.beta = path.radiance = rt_v3(0.0, 0.0, 0.0);
-    path.ray.time = 0.0;
+    path.ray.o = path.ray.d = path.beta = path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+    path.ray.time = RT_R(0.0);
     path.rng = rt_rng_make(0u, 0u, 0u, f.global_seed, RT_DOMAIN_RENDER);
     unsigned long long segs = 0;
 #ifdef RT_STAMPS
@@ -124,7 +124,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
                 rt_item_decode(f, item, px, py, chunk);
                 if (px < f.tile_w && py < f.tile_h) {
                     s = chunk * f.chunk;
-                    sum = rt_v3d(0.0, 0.0, 0.0);
+                    sum = rt_v3d(RT_R(0.0), RT_R(0.0), RT_R(0.0));
                     have = true;
                 }
             }
@@ -134,7 +134,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
         RT_STAMP(1);
         /* 2. closest hit + class */
         RtTrace tr;
-        tr.t = 0.0; tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_IDLE;
+        tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_IDLE;
         if (!retired) {
             segs += path.depth_left != 0u ? 1ull : 0ull;
             tr = rt_path_trace<Cfg>(sc, ns, path, stk);
@@ -215,7 +215,7 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
             rt_path_shade<Cfg>(sc, path, tr);
             if (!path.alive) {
                 sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
-                path.radiance = rt_v3(0.0, 0.0, 0.0);
+                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
                 ++s;
             }
         }
