@@ -246,6 +246,8 @@ def kernel_name(st):
     flags = st.get("sorted", 0)
     if flags & 4:
         return "rt_jit_sorted"
+    if flags & 128:
+        return "rt_render_kernel_pw<V%d>" % st["variant"]
     return ("rt_render_kernel_sorted<V%d>" if (flags & 1) else "rt_render_kernel<V%d>") % st["variant"]
 
 

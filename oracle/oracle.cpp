@@ -1311,6 +1311,13 @@ static HBox build_from_topology(std::vector<HBox>& leaves, TopoReader& r, Float 
         retopo_any(leaf, r); /* what the leaf holds inside follows its number */
         return leaf;
     }
+    if (code == -2) { /* BVHChild::One(obj): aabb = the object's own bounding box (bvh.rs:63-70) */
+        std::unique_ptr<BVHNode> one(new BVHNode());
+        one->time0 = t0; one->time1 = t1;
+        one->left = build_from_topology(leaves, r, t0, t1);
+        if (!r.ok || !one->left || !one->left->bounding_box(t0, t1, one->aabb)) { r.ok = false; return HBox(); }
+        return HBox(one.release());
+    }
     std::unique_ptr<BVHNode> n(new BVHNode());
     n->time0 = t0; n->time1 = t1;
     n->left = build_from_topology(leaves, r, t0, t1);

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_PLAIN_WAVES(Cfg, CACHE)) void rt_rende
     rt_render_plain_body<Cfg, CACHE>(sc, f, partial, counters);
 }
 
+/* sphere scenes (random_scene): the plain kernel with the pair walk of rt_walk_pair.h */
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_pw(RtSceneView sc, RtPwView pw, RtFrame f, double* __restrict__ partial,
+                                                                           unsigned long long* __restrict__ counters) {
+    rt_render_plain_body<Cfg, false, true>(sc, f, partial, counters, &pw);
+}
+
 /* the reordering kernel proper (rt_kernel_sorted.h) */
 template <class Cfg>
 __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
@@ -167,6 +174,11 @@ struct rt1w_context {
     int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
     void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays, built at the first f32 render */
     bool f32_tried = false, wf_recs_tried = false; std::string wf_recs_error;
+    /* pair walk (rt_walk_pair.h): records of an eligible scene (sphere-only, variant 5), the kernel's grid */
+    void* d_pw_inner = nullptr; void* d_pw_groups = nullptr;
+    RtPwView pw{};
+    bool pw_ok = false; std::string pw_why;
+    int pw_grid = 0;
     /* host copies of the flat arrays the two opt-in modes convert on first use (a scene may be destroyed before its contexts) */
     std::vector<RtNode> h_nodes, h_lights; std::vector<RtMaterial> h_materials; std::vector<RtTexture> h_textures; std::vector<RtPerlin> h_perlin;
     int f32_grid[RT_N_VARIANTS][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -300,7 +312,7 @@ void lane_destroy(RtLane& l) {
     l = RtLane();
 }
 
-struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32; };
+struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false; };
 int specialise_f32(rt1w_context* c, bool allow_compile);
 
 /* what the launch will need, without launching: frame, variant, launch shape */
@@ -367,6 +379,11 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     L.variant = variant;
     L.jit = c->jit_fn != nullptr && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED | RT1W_LDS_NODES)) && !(p->flags >> 8);
     if (L.jit) { L.sorted = true; L.cached = false; L.grid = c->jit_grid; L.block = RT_SORT_BLOCK; return RT1W_OK; }
+    /* sphere scenes: the pair walk (same frames, bit for bit), unless the caller asks for the one-entry-per-step walk */
+    if (c->pw_ok && variant == 5 && !(p->flags & (RT1W_CLASSIC_WALK | RT1W_LDS_NODES | RT1W_WAVEFRONT)) && !getenv("RT1W_CLASSIC_WALK")) {
+        L.pw = true; L.sorted = false; L.cached = false; L.grid = c->pw_grid; L.block = RT_BLOCK;
+        return RT1W_OK;
+    }
     L.sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
     L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : c->grid[variant]);
@@ -413,6 +430,8 @@ int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const
         unsigned long long* counters = l.d_counters;
         void* args[] = {&view, &frame, &partial, &counters};
         if (!hip_ok(hipModuleLaunchKernel(c->jit_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised kernel launch")) return RT1W_ERR_DEVICE;
+    } else if (L.pw) {
+        hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
     } else {
         hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : g_kernels[L.variant]),
                            dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
@@ -440,7 +459,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u);
     }
     return RT1W_OK;
 }
@@ -749,6 +768,20 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
     c->scope_depth = s->scope_depth;
     c->stack_need = s->stack_need;
     c->variant = rt_pick_variant(c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth, s->walk_annotated != 0u);
+    if (c->variant == 5 && s->stack_need + 1u <= (uint32_t)RT_PW_STACK) {
+        /* a sphere scene: records of the pair walk (rt_walk_pair.h); a scene outside its scope keeps the one-entry-per-step walk */
+        std::vector<RtPwInner> pin; std::vector<RtPwGroup> pgr;
+        if (rt_pw_build(s->flat_nodes, s->flat_root, pin, pgr, c->pw, c->pw_why)) {
+            int per_cu = 0;
+            if (!upload(&c->d_pw_inner, pin.data(), pin.size() * sizeof(RtPwInner)) || !upload(&c->d_pw_groups, pgr.data(), pgr.size() * sizeof(RtPwGroup)) ||
+                !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel_pw<RtCfgV5>, RT_BLOCK, 0), "occupancy query")) {
+                rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+            }
+            c->pw.inner = (const RtPwInner*)c->d_pw_inner; c->pw.groups = (const RtPwGroup*)c->d_pw_groups;
+            c->pw_grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+            c->pw_ok = true;
+        }
+    } else c->pw_why = "not a wrapper-free, media-free scene of more than 64 nodes, or its tree is deeper than the pair walk's stack";
     /* the opt-in modes' own data (f32 scene arrays, the wavefront form's walk records) are built at their first use:
      * ensure_f32_scene / ensure_wf_recs */
     c->h_nodes = s->flat_nodes; c->h_lights = s->flat_lights; c->h_materials = s->materials; c->h_textures = s->textures; c->h_perlin = s->perlin;
@@ -770,6 +803,8 @@ void rt1w_context_destroy(rt1w_context* c) {
     if (c->wf_hcounters) (void)hipHostFree(c->wf_hcounters);
     for (void* b : bufs) if (b) (void)hipFree(b);
     rt1w_internal_f32_destroy(c->f32_scene);
+    if (c->d_pw_inner) (void)hipFree(c->d_pw_inner);
+    if (c->d_pw_groups) (void)hipFree(c->d_pw_groups);
     lane_destroy(c->lane[0]);
     lane_destroy(c->lane[1]);
     if (c->jit_mod) (void)hipModuleUnload(c->jit_mod);

@@ -4,6 +4,27 @@
 #define RT_KERNEL_PLAIN_H
 
 #include "rt_kernel_sorted.h"
+#if !defined(RT_RNG_REFSTREAM) && !defined(RT_F32)
+#include "rt_walk_pair.h"
+#define RT_HAVE_PW 1
+#else
+#undef RT_HAVE_PW /* the reference-stream and f32 builds of this header keep the one-entry-per-step walk */
+struct RtPwView { int unused; };
+#endif
+#ifndef RT_PW_BOX_STEPS
+#define RT_PW_BOX_STEPS 6 /* inner records a lane visits per vote */
+#endif
+#ifndef RT_PW_LEAF_STEPS
+#define RT_PW_LEAF_STEPS 1 /* pending groups a lane handles per leaf vote */
+#endif
+#ifndef RT_PW_VOTES
+#define RT_PW_VOTES 8u /* lanes with a pending group that make a wave do leaf work.
+ * Tuned inside the render kernel on random_scene 1200x800x100 (kernel Mpaths/s on the reference tree / the SAH tree; the one-entry-
+ * per-step walk: 716 / 993; profiles/r03_pair_walk_tuning.txt): (box steps per vote, votes, queue entries) (1,24,4) 673 / 912,
+ * (2,24,4) 777 / 1049, (2,8,4) 833 / 1098, (2,40,4) 738 / 1020, (4,8,4) 868 / 1142, (6,8,4) 874 / 1160, (6,8,8) 883 / 1171,
+ * (8,8,8) 879 / 1156, (12,8,8) 881 / 1143; two groups per leaf vote: -3 %.  The votes cost as much as a step's bookkeeping, so a
+ * lane does several inner records per vote (as the stack walk's two steps per vote); leaf work is started as soon as 8 lanes wait. */
+#endif
 
 /* 16-bit entries (node index < 32768, wrapper-exit flag in bit 15): half the LDS, used together with
  * the LDS node cache */
@@ -39,12 +60,21 @@ struct LdsNodes {
                             2 waves (256 VGPRs, no spills) 559 / 171, 3 waves (168, spills in shading only) 662 / 188, 4 waves (128) 545 / 179 */
 #endif
 #define RT_PLAIN_WAVES(Cfg, CACHE) (Cfg::sweep && !Cfg::media ? RT_SWEEP_WAVES : (Cfg::sweep || CACHE ? 2 : RT_STACK_WAVES))
-template <class Cfg, bool CACHE>
+/* PW: the walk is the pair walk of rt_walk_pair.h (sphere scenes; `pw` = its records), else the one-entry-per-step walk */
+template <class Cfg, bool CACHE, bool PW = false>
 __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
-                                                     unsigned long long* __restrict__ counters) {
+                                                     unsigned long long* __restrict__ counters, const RtPwView* pwp = nullptr) {
     /* the sweep variants need no traversal stack (and no LDS at all) */
     typedef typename std::conditional<CACHE, uint16_t, uint32_t>::type stack_word;
-    __shared__ stack_word stack_mem[Cfg::sweep ? 1 : RT_STACK_CAP * RT_BLOCK];
+    __shared__ stack_word stack_mem[(Cfg::sweep || PW) ? 1 : RT_STACK_CAP * RT_BLOCK];
+#if defined(RT_HAVE_PW)
+    __shared__ uint32_t pw_ref[PW ? RT_PW_STACK * RT_BLOCK : 1];
+    __shared__ float pw_ent[PW ? RT_PW_STACK * RT_BLOCK : 1];
+    __shared__ uint32_t pw_q[PW ? RT_PW_QCAP * RT_BLOCK : 1];
+    RtPwLds<RT_BLOCK> pwm;
+    pwm.ref = pw_ref + threadIdx.x; pwm.ent = pw_ent + threadIdx.x; pwm.q = pw_q + threadIdx.x;
+    RtPwLane pwl; pwl.cur = RT_PW_NONE; pwl.qh = 0u; pwl.qn = 0u; pwl.sp = 0;
+#endif
     __shared__ RtNodeHot node_cache[CACHE ? RT_LDS_NODE_CAP : 1];
     typename std::conditional<CACHE, LdsStack16, LdsStack>::type stk;
     stk.base = stack_mem + threadIdx.x;
@@ -116,6 +146,83 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
             rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
             RT_STAMP(1);
         }
+#if defined(RT_HAVE_PW)
+        if constexpr (PW) {
+            /* ---- pair walk (rt_walk_pair.h) in slices: the same suspension rule as the stack walk below; what lives across a slice
+             * is the lane's next record, its stack and queue levels (stack and queue are in LDS) and the closest hit so far ---- */
+            const RtPwView& pw = *pwp;
+            if (!walking) {
+                segs += path.depth_left != 0u ? 1ull : 0ull;
+                w_best_t = RT_INF; w_best_prim = RT_NONE;
+                if (path.depth_left != 0u) {
+                    /* the root's own box first (bvh.rs:32); a NaN shutter fraction goes to the one-entry-per-step walk at once */
+                    const double frac0 = (path.ray.time - pw.ms_time0) / (pw.ms_time1 - pw.ms_time0);
+                    if (rt_isnan(frac0)) { pwl.sp = 0; pwl.qn = 0u; pwl.qh = 0u; pwl.cur = RT_PW_NONE; w_scope = 1u; walking = true; } /* w_scope 1: redo marker */
+                    else { w_scope = RT_NONE; walking = rt_pw_begin(pw, pwl, pwm, path.ray.o, rt_inv3(path.ray.d), RT_R(0.001)); }
+                }
+            }
+            RtTrace tr;
+            tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
+            if (walking) {
+                const RtV3 o = path.ray.o, d = path.ray.d, inv = rt_inv3(d);
+                const double frac = (path.ray.time - pw.ms_time0) / (pw.ms_time1 - pw.ms_time0);
+                double best_t = w_best_t;
+                uint32_t best_prim = w_best_prim;
+                bool bad = w_scope != RT_NONE;
+                const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
+                const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE(Cfg) ? lanes_here - (uint32_t)RT_SLICE_IDLE(Cfg) : 0u;
+                for (;;) {
+                    const bool more = !bad && !rt_pw_done(pwl);
+                    if (__popcll(__ballot(more)) <= stop_at) break;
+                    const bool can_box = more && rt_pw_can_box(pwl), can_leaf = more && pwl.qn > 0u;
+                    const uint32_t nb = (uint32_t)__popcll(__ballot(can_box)), nl = (uint32_t)__popcll(__ballot(can_leaf));
+                    if (nl >= RT_PW_VOTES || nb == 0u) {
+                        if (can_leaf) {
+                            rt_pw_group_step(pw, pwl, pwm, o, d, inv, frac, RT_R(0.001), best_t, best_prim);
+#pragma unroll
+                            for (int extra = 1; extra < RT_PW_LEAF_STEPS; ++extra)
+                                if (pwl.qn > 0u) rt_pw_group_step(pw, pwl, pwm, o, d, inv, frac, RT_R(0.001), best_t, best_prim);
+                            if (rt_isnan(best_t)) bad = true;
+                        }
+                    } else if (can_box) {
+                        rt_pw_box_step(pw, pwl, pwm, o, inv, RT_R(0.001), best_t);
+                        /* more records on the same vote (as the stack walk's two steps per vote: the votes cost as much as a step's bookkeeping) */
+#pragma unroll
+                        for (int extra = 1; extra < RT_PW_BOX_STEPS; ++extra)
+                            if (rt_pw_can_box(pwl)) rt_pw_box_step(pw, pwl, pwm, o, inv, RT_R(0.001), best_t);
+                    }
+                }
+                RT_STAMP(2);
+                if (bad) {
+                    /* the closest hit turned NaN (a NaN root is accepted, sphere.rs:43-48): monotonicity is gone, the segment is redone
+                     * by the one-entry-per-step walk on the same LDS words (no random draws in this scene's walk: nothing to restore) */
+                    LdsStack cs;
+                    cs.base = pw_ref + threadIdx.x; cs.sp = 0;
+                    uint32_t scope_;
+                    rt_traverse_stack<Cfg, true>(sc, ns, sc.root, path.ray, RT_R(0.001), RT_INF, path.rng, cs, best_t, best_prim, scope_);
+                    pwl.cur = RT_PW_NONE; pwl.sp = 0; pwl.qn = 0u; w_scope = RT_NONE;
+                }
+                if (rt_pw_done(pwl)) {
+                    walking = false;
+                    tr.t = best_t; tr.prim = best_prim; tr.scope = RT_NONE;
+                    if (tr.prim != RT_NONE) {
+                        const uint32_t mk = RT_MAT_KINDF(ns.hot(tr.prim).mat) & 0xFFu;
+                        tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
+                               : mk == RT_MAT_METAL ? RT_CLS_METAL : mk == RT_MAT_ISOTROPIC ? RT_CLS_OTHER : RT_CLS_TERMINAL;
+                    }
+                } else {
+                    w_best_t = best_t; w_best_prim = best_prim;
+                }
+            }
+            if (!walking) {
+                rt_path_shade<Cfg>(sc, path, tr);
+                if (!path.alive) {
+                    sum = rt_v3d_add(sum, path.radiance);
+                    ++s;
+                }
+            }
+        } else
+#endif
         if constexpr (!Cfg::sweep && RT_SLICE_IDLE(Cfg) > 0 && RT_WALK_MODE == 0) {
             /* ---- stack walk in slices ------------------------------------------------------------------------------
              * Walk lengths within a wave differ wildly (final_scene: 40 node visits per segment on average, several hundred

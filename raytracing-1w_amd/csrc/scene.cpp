@@ -191,9 +191,28 @@ struct Flattener {
         if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), items.begin() + (long)lo);
         return lo + best_i;
     }
+    /* `lone`: this range is one object whose sibling is a subtree.  BVHNode::new never hangs a bare object next to a subtree: a
+     * one-object half becomes BVHChild::One with the object's own box (bvh.rs:63-70), so that every object sits under a One or under
+     * a two-object Two.  The rebuilt trees keep that shape (stream code -2): the object is tested behind its own box, as in the
+     * reference's trees, and the phased pair walk (rt_walk_pair.h) finds every primitive in a primitive group. */
     uint32_t emit_sah(std::vector<SahItem>& items, size_t lo, size_t hi, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary,
-                      uint32_t* need) {
+                      uint32_t* need, bool lone = false) {
         if (hi - lo == 1) {
+            if (lone) {
+                if (topo) topo->push_back(-2);
+                const uint32_t idx = (uint32_t)out.size();
+                RtNode n = blank(RT_BVH1);
+                const AABB& box = items[lo].box;
+                n.d[0] = box.minimum.x; n.d[1] = box.minimum.y; n.d[2] = box.minimum.z;
+                n.d[3] = box.maximum.x; n.d[4] = box.maximum.y; n.d[5] = box.maximum.z;
+                out.push_back(n);
+                if (topo) topo->push_back(items[lo].orig);
+                uint32_t na = 0;
+                const uint32_t a = emit(items[lo].id, parent_scope, scope_depth, in_boundary, &na);
+                out[idx].a = a;
+                *need = std::max(2u, na);
+                return idx;
+            }
             if (topo) topo->push_back(items[lo].orig);
             return emit(items[lo].id, parent_scope, scope_depth, in_boundary, need);
         }
@@ -209,8 +228,9 @@ struct Flattener {
         n.d[3] = box.maximum.x; n.d[4] = box.maximum.y; n.d[5] = box.maximum.z;
         out.push_back(n);
         uint32_t na = 0, nb = 0;
-        const uint32_t a = emit_sah(items, lo, mid, parent_scope, scope_depth, in_boundary, &na);
-        const uint32_t b = emit_sah(items, mid, hi, parent_scope, scope_depth, in_boundary, &nb);
+        const bool mixed = (mid - lo == 1) != (hi - mid == 1); /* one object next to a subtree */
+        const uint32_t a = emit_sah(items, lo, mid, parent_scope, scope_depth, in_boundary, &na, mixed && mid - lo == 1);
+        const uint32_t b = emit_sah(items, mid, hi, parent_scope, scope_depth, in_boundary, &nb, mixed && hi - mid == 1);
         out[idx].a = a; out[idx].b = b;
         *need = std::max(2u, std::max(1u + na, nb));
         return idx;

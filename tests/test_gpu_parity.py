@@ -685,3 +685,37 @@ def test_wavefront_depth_edge_cases(rt, gpu_ctx_factory):
         assert (sb["sorted"] & 8) and sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), depth
     with pytest.raises(rt.Rt1wError):
         ctx.render(72, 48, 2, max_depth=65, wavefront=True)          # beyond WF_MAX_BOUNCES: refused, not silently different
+
+
+def test_pair_walk_of_sphere_scenes_is_bit_identical(rt, gpu_ctx_factory):
+    """Sphere scenes (random_scene, BASELINE C2) walk their BVH with the pair walk of csrc/rt_walk_pair.h by default: box work and
+    leaf work in separate wave phases, inner boxes in f32 rounded outward, every sphere gated by its group's own f64 box at the
+    reference's moment.  The frame must equal the one-entry-per-step walk's (RT1W_CLASSIC_WALK) and the CPU build of the core,
+    bit for bit, with equal segment counts -- on the reference's tree and on the SAH tree, at sizes where lanes suspend and
+    resume their walks (slices) and take new work items."""
+    for sah in (False, True):
+        sc = rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5)
+        if sah:
+            sc.set_bvh_build(True)
+        ctx = gpu_ctx_factory(sc)
+        for W, H, spp in ((96, 64, 8), (600, 400, 3)):
+            a, sa = ctx.render(W, H, spp)
+            b, sb = ctx.render(W, H, spp, classic_walk=True)
+            assert sa["sorted"] & 128 and not (sb["sorted"] & 128), (sa["sorted"], sb["sorted"])
+            assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, W, H, spp)
+        cpu, sc_ = orc.flat_render(sc, 96, 64, 8, chunk=rt.default_chunk(96, 64, 8))
+        a, sa = ctx.render(96, 64, 8)
+        assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), sah
+        ctx.close()
+    # other build seeds (other trees, other sphere placements), a tile, a sample offset
+    for seed in (2, 3):
+        sc = rt.Scene.reference(0, build_seed=seed, aspect_ratio=1.5)
+        ctx = gpu_ctx_factory(sc)
+        a, sa = ctx.render(300, 200, 4, tile=(16, 8, 200, 120), sample_offset=3)
+        b, sb = ctx.render(300, 200, 4, tile=(16, 8, 200, 120), sample_offset=3, classic_walk=True)
+        assert sa["sorted"] & 128 and sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), seed
+        ctx.close()
+    # a scene the pair walk does not cover keeps the one-entry-per-step walk
+    ctx = gpu_ctx_factory(rt.Scene.reference(7, build_seed=1))
+    _, st = ctx.render(32, 32, 2)
+    assert not (st["sorted"] & 128)
