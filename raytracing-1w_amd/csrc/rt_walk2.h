@@ -39,7 +39,7 @@
 #define RT_W2_PGROUP 0x20000000u /* reference to a primitive group (low bits: index of the BVH node in the flat node array) */
 #define RT_W2_INDEX 0x1FFFFFFFu
 #define RT_W2_NONE 0xFFFFFFFFu   /* no entry (never a valid reference: RT_POP_FLAG | INNER | PGROUP all set) */
-#define RT_W2_QCAP 4             /* pending primitive groups per lane */
+#define RT_W2_QCAP 4             /* pending primitive groups per lane (a power of two; 8 costs the lab kernel a workgroup per CU) */
 #define RT_W2_STACK 24           /* stack entries per lane the phased kernels are built with (deeper scenes keep the classic walk) */
 
 struct RtW2Inner {

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(LAB_W1_BLOCK, LDS_INNER ? (F32 ? 3 : 2) : (F32 ? 4 
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w2(RtSceneView sc, RtW2View w2, const LabRay* __restrict__ rays, unsigned long long n,
                                                             LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
-                                                            uint32_t leaf_votes, unsigned long long* stats) {
+                                                            uint32_t leaf_votes, unsigned long long* stats, uint32_t box_steps) {
     __shared__ uint32_t s_ref[RT_W2_STACK * RT_BLOCK];
     __shared__ float s_ent[RT_W2_STACK * RT_BLOCK];
     __shared__ uint32_t s_q[RT_W2_QCAP * RT_BLOCK];
@@ -577,7 +577,14 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w2(RtSceneView sc, RtW2
             }
             ++w_leaf;
         } else {
-            if (can_box) { rt_w2_box_step<RtW2Stack<RT_BLOCK>, RT_BLOCK>(w2, L, k, stk); ++n_box; }
+            if (can_box) {
+                rt_w2_box_step<RtW2Stack<RT_BLOCK>, RT_BLOCK>(w2, L, k, stk); ++n_box;
+                for (uint32_t extra = 1; extra < box_steps; ++extra) { /* more box work on the same vote (rt_kernel_plain.h: RT_PW_BOX_STEPS) */
+                    rt_w2_refetch<RtW2Stack<RT_BLOCK>, RT_BLOCK>(L, k, stk);
+                    if (!(rt_w2_is_boxwork(L.cur) && stk.qn + 2u <= (uint32_t)RT_W2_QCAP)) break;
+                    rt_w2_box_step<RtW2Stack<RT_BLOCK>, RT_BLOCK>(w2, L, k, stk); ++n_box;
+                }
+            }
             ++w_box;
         }
         if (walking) {
@@ -888,7 +895,7 @@ int rt1w_lab_set_rays(rt1w_lab* l, const double* rays, uint64_t n) {
     return RT1W_OK;
 }
 
-/* params: [0] refill_idle (lanes), [1] leaf_votes (W1), [2] blocks per CU (0: the occupancy query's) */
+/* params: [0] refill_idle (lanes), [1] leaf_votes (W1, W2), [2] blocks per CU (0: the occupancy query's), [3] box steps per vote (W2) */
 int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats, double* out_t, uint32_t* out_prim, uint32_t* out_flags,
                    double* ms_best, uint64_t stats_out[8]) {
     if (!l || !l->d_rays) { rt1w::set_error("no rays set"); return RT1W_ERR_STATE; }
@@ -901,6 +908,7 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
+    const uint32_t box_steps = params && params[3] ? params[3] : 1u;
     int per_cu = 0;
     const void* fn = nullptr;
     if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
@@ -922,9 +930,9 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
             else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else hipLaunchKernelGGL(lab_trace_w0<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
         } else if (mode == 6) {
-            if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w2<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1);
-            else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w2<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1);
-            else hipLaunchKernelGGL(lab_trace_w2<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1);
+            if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w2<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, box_steps);
+            else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w2<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, box_steps);
+            else hipLaunchKernelGGL(lab_trace_w2<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->w2, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, votes, l->d_counter + 1, box_steps);
         } else if (mode == 3) {
             if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0q<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0q<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);

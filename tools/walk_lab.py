@@ -53,8 +53,8 @@ class Lab:
         rt._ck(L.rt1w_lab_set_rays(self._h, r.ctypes.data_as(_P), r.shape[0]))
         self.n = r.shape[0]
 
-    def trace(self, mode, refill=16, votes=24, blocks_per_cu=0, repeats=3, want_hits=True):
-        prm = (C.c_uint32 * 4)(refill, votes, blocks_per_cu, 0)
+    def trace(self, mode, refill=16, votes=24, blocks_per_cu=0, repeats=3, want_hits=True, box_steps=1):
+        prm = (C.c_uint32 * 4)(refill, votes, blocks_per_cu, box_steps)
         t = np.empty(self.n, dtype=np.float64)
         prim = np.empty(self.n, dtype=np.uint32)
         flags = np.empty(self.n, dtype=np.uint32)
@@ -133,10 +133,10 @@ def main():
                     print(f"      {label:28s} {r['stats'][7]} workgroups/CU: {n / r['ms'] / 1e3:8.1f} Mrays/s")
                     if r['stats'][7] < bpc:
                         break
-        for votes in (8, 24, 40):
-            c = min((lab.trace(6, refill=rf, votes=votes) for rf in (32, 48)), key=lambda r: r["ms"])
+        for votes, bs in ((24, 1), (8, 1), (8, 4), (8, 6), (4, 6), (16, 6)):
+            c = min((lab.trace(6, refill=rf, votes=votes, box_steps=bs) for rf in (32, 48)), key=lambda r: r["ms"])
             st = c["stats"]
-            print(f"\n      W2 phased walk votes {votes:2d}: {n / c['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / c['ms']:.2f}x)  per ray: inner {st[0] / n:5.1f} groups {st[2] / n:5.1f} other {st[4] / n:5.2f}  "
+            print(f"\n      W2 phased walk votes {votes:2d} box steps {bs}: {n / c['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / c['ms']:.2f}x)  per ray: inner {st[0] / n:5.1f} groups {st[2] / n:5.1f} other {st[4] / n:5.2f}  "
                   f"wave-steps/64 rays box {st[1] * 64 / n:6.1f} leaf {st[3] * 64 / n:6.1f}  handed back {int((c['flags'] & 1).sum())}  wg/CU {st[7]}  hits equal W0: {same_hits(base, c)}", end="")
         if lab.w1_ok:
             for votes in (8, 24, 40):
