@@ -153,4 +153,17 @@ uint32_t orcflat_sizeof(int what) {
                     case 3: return sizeof(RtPerlin); case 4: return sizeof(RtCamera); case 5: return sizeof(RtFrame); default: return 0; }
 }
 
+/* rt_rng_mark / rt_rng_rewind (include/rt1w_num.h): after `before` mixed draws the stream is marked, `n` words are drawn into
+ * out_a, the stream is rewound to the mark and the same `n` words drawn into out_b: they must be equal.  Bit i of `pattern`
+ * picks a 32-bit (0) or 64-bit (1) draw for draw i (mod 32).  Built for the Philox streams and, in liborc_flat_ref.so, for
+ * the reference's ChaCha12 stream. */
+void orcflat_rng_rewind_check(uint64_t seed, uint32_t pattern, uint32_t before, uint32_t n, uint64_t* out_a, uint64_t* out_b) {
+    RtRng r = rt_rng_pixel_sample(seed, 3u, 7u);
+    for (uint32_t i = 0; i < before; ++i) { if ((pattern >> (i & 31u)) & 1u) (void)rt_next_u64(r); else (void)rt_next_u32(r); }
+    const RtRngMark m = rt_rng_mark(r);
+    for (uint32_t i = 0; i < n; ++i) out_a[i] = ((pattern >> ((i + before) & 31u)) & 1u) ? rt_next_u64(r) : (uint64_t)rt_next_u32(r);
+    rt_rng_rewind(r, m);
+    for (uint32_t i = 0; i < n; ++i) out_b[i] = ((pattern >> ((i + before) & 31u)) & 1u) ? rt_next_u64(r) : (uint64_t)rt_next_u32(r);
+}
+
 } /* extern "C" */

@@ -109,3 +109,20 @@ def test_floor_and_tan():
     assert np.array_equal(num_eval(9, x), np.floor(x))
     t = rng.uniform(-1.5, 1.5, 2000)
     assert ulps(num_eval(10, t), mpref(mp.tan, t)).max() <= 3.0
+
+
+def test_rng_mark_and_rewind_reproduce_the_word_stream():
+    """rt_rng_mark / rt_rng_rewind (the phased walk's restart, csrc/rt_walk2.h): the buffered words are regenerated from the
+    counter, so drawing on from a rewound stream gives the very words drawn after the mark -- at every buffer position, for mixed
+    32- and 64-bit draws, in the Philox build and in the reference-stream (ChaCha12) build of the header."""
+    import ctypes as C
+    for lib in (orc.B, orc.flat_ref_lib()):
+        lib.orcflat_rng_rewind_check.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        g = np.random.default_rng(5)
+        for before in list(range(0, 24)) + [100, 257]:
+            for pattern in (0, 0xFFFFFFFF, int(g.integers(0, 1 << 32)), int(g.integers(0, 1 << 32))):
+                a = np.zeros(40, dtype=np.uint64)
+                b = np.ones(40, dtype=np.uint64)
+                lib.orcflat_rng_rewind_check(int(g.integers(0, 1 << 40)), pattern, before, 40, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(a, b), (before, hex(pattern))
+                assert len(set(a.tolist())) > 30
