@@ -719,3 +719,16 @@ def test_pair_walk_of_sphere_scenes_is_bit_identical(rt, gpu_ctx_factory):
     ctx = gpu_ctx_factory(rt.Scene.reference(7, build_seed=1))
     _, st = ctx.render(32, 32, 2)
     assert not (st["sorted"] & 128)
+
+
+def test_precompiled_kernels_load_on_a_host_without_the_runtime_compiler(rt):
+    """A host that cannot compile (no libhiprtc: RT1W_NO_HIPRTC hides it) still runs the scene-specialised kernels the build
+    precompiled under <package>/kernels -- their key no longer contains the host's compiler id (round-2 advice)."""
+    import subprocess
+    import sys
+    code = ("import importlib, sys; sys.path.insert(0, %r); rt = importlib.import_module('raytracing-1w_amd'); "
+            "ctx = rt.Context(rt.Scene.reference(5, build_seed=1), 0); i = ctx.specialise(cached_only=True); "
+            "g, st = ctx.render(32, 32, 2); print(int(i['active']), int(i['from_cache']), st['sorted'] & 4)" % orc.ROOT)
+    env = dict(os.environ, RT1W_NO_HIPRTC="1", RT1W_KERNEL_CACHE="/nonexistent-rt1w-cache")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
+    assert out == ["1", "1", "4"], out

@@ -65,3 +65,26 @@ def test_unrolled_sweep_equals_generic_sweep(static_lib):
         b, sb = orc.flat_render(sc, W, H, spp, chunk=3, variant=100 + k, lib=lib)
         assert sa["segments"] == sb["segments"], name
         assert np.array_equal(a, b, equal_nan=True), name
+
+
+def test_kernel_key_does_not_depend_on_the_host_compiler(rt):
+    """The kernels under <package>/kernels were compiled by the build for this very library: their key is source + headers + options,
+    NOT the hiprtc of the host that runs them (round-2 advice: with the toolchain id in the key a host without libhiprtc, or with
+    another minor release, silently fell back to the generic kernels).  The key is the same with the run-time compiler hidden
+    (RT1W_NO_HIPRTC), and the build's precompiled kernel of the Cornell arm is there under that key."""
+    import os
+    import subprocess
+    import sys
+    code = ("import importlib, sys; sys.path.insert(0, %r); rt = importlib.import_module('raytracing-1w_amd'); "
+            "print(rt.Scene.reference(5, build_seed=1).kernel_key())" % orc.ROOT)
+    keys = []
+    for hide in (False, True):
+        env = dict(os.environ)
+        env.pop("RT1W_NO_HIPRTC", None)
+        if hide:
+            env["RT1W_NO_HIPRTC"] = "1"
+        keys.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip())
+    assert keys[0] == keys[1] and len(keys[0]) == 16
+    kdir = os.path.join(orc.ROOT, "raytracing-1w_amd", "kernels")
+    if os.path.isdir(kdir):   # filled by build(); absent only if hiprtc was unavailable at build time
+        assert os.path.exists(os.path.join(kdir, "sweep_%s.hsaco" % keys[0])), os.listdir(kdir)
