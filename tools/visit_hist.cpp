@@ -10,7 +10,7 @@ static thread_local unsigned long long g_hist[16];
 #define RT_STAT_VISIT(kind) do { ++g_hist[(kind) & 15]; } while (0)
 #include "rt_core.h"
 #include "rt1w.h"
-struct HostStack { uint32_t e[64]; int sp = 0; void push(uint32_t v) { e[sp++] = v; } uint32_t pop() { return e[--sp]; } };
+struct HostStack { uint32_t e[64]; int sp = 0; void push(uint32_t v) { e[sp++] = v; } void poke(int above, uint32_t v) { e[sp + above] = v; } uint32_t pop() { return e[--sp]; } };
 struct cam_bg { RtCamera cam; RtV3 bg; uint32_t root, pad; };
 int main(int argc, char** argv) {
     int arm = atoi(argv[1]), W = atoi(argv[2]), H = atoi(argv[3]), spp = atoi(argv[4]);
