@@ -564,6 +564,22 @@ RT_HD void rt_walk_step(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& r
     rt_walk_visit<Cfg, MEDIA>(sc, ns, k, rng, stk, e, nd);
 }
 
+/* a step that only a BVH node takes: the lane pops its next entry and, if that is a BVH node, tests its box and pushes the children;
+ * any other entry is put back untouched and waits for the next full step.  Same visits, same order per lane -- it only lets the
+ * lanes that are between boxes (84 % of final_scene's visits) advance several nodes for each execution of the rare kinds' code
+ * (media, wrappers, primitives), which a full step runs for two or three lanes of the wave. */
+template <class Cfg, class Stack, class NS>
+RT_HD bool rt_walk_box_step(const NS& ns, RtWalk& k, Stack& stk) {
+    const uint32_t e = stk.pop();
+    bool taken = false;
+    if (!(Cfg::scope_depth > 0 && (e & RT_POP_FLAG))) {
+        const RtNodeHot nd = ns.hot(e);
+        if ((nd.kind & RT_KIND_MASK) <= RT_BVH1) { RT_STAT_VISIT(nd.kind & RT_KIND_MASK); rt_walk_box<Cfg, false>(k, e, nd, stk); taken = true; }
+    }
+    if (!taken) stk.sp += 1; /* the entry is still where it was */
+    return taken;
+}
+
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,

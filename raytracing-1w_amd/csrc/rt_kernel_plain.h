@@ -14,6 +14,9 @@ struct RtPwView { int unused; };
 #ifndef RT_PW_BOX_STEPS
 #define RT_PW_BOX_STEPS 6 /* inner records a lane visits per vote */
 #endif
+#ifndef RT_MEDIA_PREFILL
+#define RT_MEDIA_PREFILL 1
+#endif
 #ifndef RT_PW_LEAF_STEPS
 #define RT_PW_LEAF_STEPS 1 /* pending groups a lane handles per leaf vote */
 #endif
@@ -47,6 +50,16 @@ struct LdsNodes {
 /* stack walk: finished lanes of a wave that end a slice of the walk (0: every walk runs to its end).  Measured (Mpaths/s at 48 spp): media-free
  * kernels (two steps per vote) 40: 636, 48: 662, 56: 675; media kernels 40: 190, 48: 191, 56: 189 */
 #define RT_SLICE_IDLE(Cfg) (Cfg::media ? 48 : 56)
+#endif
+#ifndef RT_SLICE_BOX_MIN_LANES
+#define RT_SLICE_BOX_MIN_LANES 0
+#endif
+#ifndef RT_SLICE_BOX_STEPS
+/* box-only steps per vote of the sliced stack walk (rt_walk_box_step): scenes with media only -- their full step is long (a medium is two
+ * sphere tests, a logarithm and a draw) and 84 % of final_scene's visits are boxes.  Measured, final_scene 800x800x100, kernel Mpaths/s
+ * (profiles/r03_box_steps.txt): 0: 215, 3: 229, 4: 251, 5: 247, 6: 243 (234 with the wait flag), 8: 224, 10: 212-215, 16: 186; a run-time
+ * loop that ends once fewer than 16-40 lanes are still between boxes: 227-242 */
+#define RT_SLICE_BOX_STEPS(Cfg) (Cfg::media ? 4 : 0)
 #endif
 #ifndef RT_SLICE_TWO_STEPS
 #define RT_SLICE_TWO_STEPS(Cfg) (!Cfg::media)
@@ -235,7 +248,15 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
             if (!walking) {
                 segs += path.depth_left != 0u ? 1ull : 0ull;
                 w_best_t = RT_INF; w_best_prim = RT_NONE; w_best_scope = RT_NONE; w_scope = RT_NONE;
-                if (path.depth_left != 0u) { stk.push(sc.root); walking = true; }
+                if (path.depth_left != 0u) {
+                    stk.push(sc.root); walking = true;
+#if RT_MEDIA_PREFILL
+                    /* a ConstantMedium draws inside the walk (constant_medium.rs:85) -- for two or three lanes of a wave at a time, and a
+                     * draw that finds the buffer empty generates a Philox block there.  Generate it here, where every starting lane
+                     * takes part; the word stream is the same (blocks are only made earlier) */
+                    if (Cfg::media) rt_rng_fill(path.rng);
+#endif
+                }
             }
             RtTrace tr;
             tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = RT_CLS_TERMINAL;
@@ -257,6 +278,15 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                     /* a second step on the same vote where a step is cheap (measured: random_scene +1.8 %; final_scene, whose steps
                      * can be a whole medium, -4 %) */
                     if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
+                    /* box-only steps on the same vote (rt_walk_box_step) */
+                    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {
+                        bool between_boxes = true; /* until the lane's next entry is something else: it then waits for the next full step */
+                        for (int extra = 0; extra < RT_SLICE_BOX_STEPS(Cfg); ++extra) {
+                            const bool go = between_boxes && !rt_walk_done(k, stk);
+                            if (RT_SLICE_BOX_MIN_LANES > 0 && (uint32_t)__popcll(__ballot(go)) < (uint32_t)RT_SLICE_BOX_MIN_LANES) break; /* too few lanes still between boxes */
+                            if (go) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);
+                        }
+                    }
                 }
                 RT_STAMP(2);
                 if (rt_walk_done(k, stk)) {
