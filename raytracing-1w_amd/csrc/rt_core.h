@@ -580,6 +580,20 @@ RT_HD bool rt_walk_box_step(const NS& ns, RtWalk& k, Stack& stk) {
     return taken;
 }
 
+/* the same for a primitive (sphere, moving sphere, rect): a step that only a lane whose next entry is a primitive takes */
+template <class Cfg, class Stack, class NS>
+RT_HD bool rt_walk_prim_step(const RtSceneView& sc, const NS& ns, RtWalk& k, Stack& stk) {
+    const uint32_t e = stk.pop();
+    bool taken = false;
+    if (!(Cfg::scope_depth > 0 && (e & RT_POP_FLAG))) {
+        const RtNodeHot nd = ns.hot(e);
+        const uint32_t km = nd.kind & RT_KIND_MASK;
+        if (km > RT_BVH1 && km <= RT_YZ) { RT_STAT_VISIT(km); rt_walk_leaf<Cfg>(sc, k, e, nd); taken = true; }
+    }
+    if (!taken) stk.sp += 1;
+    return taken;
+}
+
 template <class Cfg, bool MEDIA, class Stack, class NS>
 RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root, const RtRay& world, double t_min,
                              double t_max, RtRng& rng, Stack& stk, double& out_t, uint32_t& out_prim,

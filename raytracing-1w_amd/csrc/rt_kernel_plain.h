@@ -48,8 +48,12 @@ struct LdsNodes {
 
 #ifndef RT_SLICE_IDLE
 /* stack walk: finished lanes of a wave that end a slice of the walk (0: every walk runs to its end).  Measured (Mpaths/s at 48 spp): media-free
- * kernels (two steps per vote) 40: 636, 48: 662, 56: 675; media kernels 40: 190, 48: 191, 56: 189 */
-#define RT_SLICE_IDLE(Cfg) (Cfg::media ? 48 : 56)
+ * kernels (two steps per vote) 40: 636, 48: 662, 56: 675; media kernels 40: 190, 48: 191, 56: 189 (round 2); with the box-only steps of
+ * round 3 (100 spp): 24: 244, 32: 253, 36: 253, 40: 254, 48: 251, 56: 236, 60: 222 */
+#define RT_SLICE_IDLE(Cfg) (Cfg::media ? 40 : 56)
+#endif
+#ifndef RT_SLICE_PRIM_STEPS
+#define RT_SLICE_PRIM_STEPS 0 /* a primitive-only step + n more box steps behind the box steps: measured 247-249 against 252 Mpaths/s, off */
 #endif
 #ifndef RT_SLICE_BOX_MIN_LANES
 #define RT_SLICE_BOX_MIN_LANES 0
@@ -286,6 +290,13 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                             if (RT_SLICE_BOX_MIN_LANES > 0 && (uint32_t)__popcll(__ballot(go)) < (uint32_t)RT_SLICE_BOX_MIN_LANES) break; /* too few lanes still between boxes */
                             if (go) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);
                         }
+#if RT_SLICE_PRIM_STEPS
+                        /* then one primitive-only step and more box steps behind it */
+                        if (!rt_walk_done(k, stk)) between_boxes = rt_walk_prim_step<Cfg>(sc, ns, k, stk) || between_boxes;
+#pragma unroll
+                        for (int extra = 0; extra < RT_SLICE_PRIM_STEPS; ++extra)
+                            if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);
+#endif
                     }
                 }
                 RT_STAMP(2);

@@ -14,6 +14,8 @@
  *
  * Walks:
  *   mode 0  W0: the product's stack walk (rt_walk_begin / rt_walk_step of rt_core.h), one stack entry per step.
+ *   mode 7  W0b: W0 with four box-only steps behind every full step (rt_walk_box_step): a lane between boxes advances several nodes
+ *           per execution of the rare kinds' code.  In the product for scenes with media (rt_kernel_plain.h: RT_SLICE_BOX_STEPS).
  *   mode 3  W0q: W0 with the node records fetched by quads (four lanes share each 64-byte access) and transposed with DPP.
  *   mode 6  W2: the phased walk of rt_walk2.h -- W1's two phases for EVERY scene (wrappers, media, rects, nested BVHs), inner boxes
  *           in f32 rounded outward; what the product's stack-walk kernels are to run.
@@ -102,7 +104,7 @@ __device__ __forceinline__ unsigned long long lab_fetch(bool want, unsigned long
 /* ------------------------------------------------------------------------------------------------- W0 -- */
 
 /* the product's walk, one entry per step; idle lanes refill once `refill_idle` of them wait (or nothing else can step) */
-template <class Cfg>
+template <class Cfg, int BOXSTEPS = 0>
 __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, const LabRay* __restrict__ rays, unsigned long long n,
                                                             LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
                                                             unsigned long long* stats) {
@@ -140,6 +142,12 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, cons
         if (walking) {
             rt_walk_step<Cfg, true>(sc, ns, k, rng, stk);
             ++steps;
+            if constexpr (BOXSTEPS > 0) { /* W0b: box-only steps behind the full step (rt_walk_box_step; what the render kernels of media scenes do) */
+                bool between_boxes = true;
+#pragma unroll
+                for (int extra = 0; extra < BOXSTEPS; ++extra)
+                    if (between_boxes && !rt_walk_done(k, stk)) { between_boxes = rt_walk_box_step<Cfg>(ns, k, stk); steps += between_boxes ? 1ull : 0ull; }
+            }
             if (rt_walk_done(k, stk)) walking = false;
         }
         ++wave_steps;
@@ -904,14 +912,15 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 6 && !l->w2_ok) { rt1w::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 6) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (mode < 0 || mode > 7) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
     const uint32_t box_steps = params && params[3] ? params[3] : 1u;
     int per_cu = 0;
     const void* fn = nullptr;
-    if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
+    if (mode == 7) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4> : (const void*)lab_trace_w0<RtCfgV2, 4>);
+    else if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
     else if (mode == 3) fn = l->variant == 5 ? (const void*)lab_trace_w0q<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0q<RtCfgV3> : (const void*)lab_trace_w0q<RtCfgV2>);
     else if (mode == 6) fn = l->variant == 5 ? (const void*)lab_trace_w2<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w2<RtCfgV3> : (const void*)lab_trace_w2<RtCfgV2>);
     else if (mode == 4) fn = (const void*)lab_trace_w1<false, true>;
@@ -925,7 +934,11 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     for (int rep = 0; rep < (repeats > 0 ? repeats : 1); ++rep) {
         (void)hipMemsetAsync(l->d_counter, 0, 16 * sizeof(unsigned long long), l->stream);
         (void)hipEventRecord(l->ev0, l->stream);
-        if (mode == 0) {
+        if (mode == 7) {
+            if (l->variant == 5) hipLaunchKernelGGL((lab_trace_w0<RtCfgV5, 4>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else if (l->variant == 3) hipLaunchKernelGGL((lab_trace_w0<RtCfgV3, 4>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else hipLaunchKernelGGL((lab_trace_w0<RtCfgV2, 4>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+        } else if (mode == 0) {
             if (l->variant == 5) hipLaunchKernelGGL(lab_trace_w0<RtCfgV5>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL(lab_trace_w0<RtCfgV3>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else hipLaunchKernelGGL(lab_trace_w0<RtCfgV2>, dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
