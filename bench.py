@@ -225,9 +225,28 @@ def git_head():
         return None
 
 
+KERNEL_SOURCES = ("include/rt1w_num.h", "raytracing-1w_amd/csrc/rt_flat.h", "raytracing-1w_amd/csrc/rt_core.h",
+                  "raytracing-1w_amd/csrc/rt_kernel_sorted.h", "raytracing-1w_amd/csrc/rt_kernel_plain.h",
+                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/context.hip")
+
+
+def kernel_sources_id():
+    """identity of the render kernels' source text (the files the f64 kernels are compiled from): what a stored PMC measurement
+    is matched against -- a commit would not do, committing the measurement itself moves it"""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for f in KERNEL_SOURCES:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+    except OSError:
+        return None
+    return h.hexdigest()[:12]
+
+
 def stored_pmc(workload, kernel, spec_key):
     """Stored PMC figures (separate rocprofv3 --pmc passes, profiles/pmc_summary.json), attached only when they were taken on
-    the kernel that just ran.  valu_lane_issue_frac = VALU-busy fraction of the SIMD cycles x active lanes per VALU
+    the kernel that just ran: same kernel name, same kernel source text (kernel_sources_id), same specialisation key.
+    valu_lane_issue_frac = VALU-busy fraction of the SIMD cycles x active lanes per VALU
     instruction / 64: the share of the f64 VALU lane-issue capacity doing work -- the kernel's true limiter."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
@@ -236,7 +255,8 @@ def stored_pmc(workload, kernel, spec_key):
         return None
     if not ent:
         return None
-    same = ent.get("kernel") == kernel and (ent.get("specialise_key") in (None, spec_key))
+    same = (ent.get("kernel") == kernel and ent.get("specialise_key") in (None, spec_key) and
+            ent.get("kernel_sources") is not None and ent.get("kernel_sources") == kernel_sources_id())
     ent = dict(ent, matches_this_run=bool(same), file="profiles/pmc_summary.json")
     ent.pop("kernel_names_seen", None)
     return ent
@@ -462,7 +482,7 @@ def rank_main(a, be=None):
                                           else "1 GPU, D2H into a pinned host frame",
                            "host_frame_pinned": bool(frame._pinned) if frame is not None else True,
                            "host_frame_pin_error": getattr(frame, "pin_error", None) if frame is not None else None,
-                           "backend": be.name, "commit": git_head()},
+                           "backend": be.name, "commit": git_head(), "kernel_sources": kernel_sources_id()},
                 "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
                 "roofline": roofline_block(a.workload if (world == 1 and a.bvh == "reference" and a.walk_order == "reference") else None, st, avg_ms,
                                            my_pixels, spec.get("key") if spec else None, spp),

@@ -55,6 +55,9 @@ struct LdsNodes {
 #ifndef RT_SLICE_PRIM_STEPS
 #define RT_SLICE_PRIM_STEPS 0 /* a primitive-only step + n more box steps behind the box steps: measured 247-249 against 252 Mpaths/s, off */
 #endif
+#ifndef RT_SLICE_HEAVY_EVERY
+#define RT_SLICE_HEAVY_EVERY 1 /* n > 1: only every n-th full step of a media kernel takes ConstantMedium entries (rt_walk_light_step in between) */
+#endif
 #ifndef RT_SLICE_BOX_MIN_LANES
 #define RT_SLICE_BOX_MIN_LANES 0
 #endif
@@ -275,13 +278,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 RT_STAMP(7); /* bucket 7 here: rebuilding the walk's rays */
                 const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
                 const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE(Cfg) ? lanes_here - (uint32_t)RT_SLICE_IDLE(Cfg) : 0u;
-                for (;;) {
-                    const bool more = !rt_walk_done(k, stk);
-                    if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
-                    if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
-                    /* a second step on the same vote where a step is cheap (measured: random_scene +1.8 %; final_scene, whose steps
-                     * can be a whole medium, -4 %) */
-                    if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
+                auto box_steps = [&]() {
                     /* box-only steps on the same vote (rt_walk_box_step) */
                     if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {
                         bool between_boxes = true; /* until the lane's next entry is something else: it then waits for the next full step */
@@ -297,6 +294,25 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                         for (int extra = 0; extra < RT_SLICE_PRIM_STEPS; ++extra)
                             if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);
 #endif
+                    }
+                };
+                for (bool stop = false; !stop;) {
+                    const bool more = !rt_walk_done(k, stk);
+                    if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
+                    if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
+                    /* a second step on the same vote where a step is cheap (measured: random_scene +1.8 %; final_scene, whose steps
+                     * can be a whole medium, -4 %) */
+                    if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
+                    box_steps();
+                    if constexpr (Cfg::media && RT_SLICE_HEAVY_EVERY > 1) {
+                        /* then rounds whose full step leaves media alone (rt_walk_light_step) */
+#pragma unroll
+                        for (int r = 1; r < RT_SLICE_HEAVY_EVERY; ++r) {
+                            const bool more2 = !rt_walk_done(k, stk);
+                            if (__popcll(__ballot(more2)) <= stop_at) { stop = true; break; }
+                            if (more2) rt_walk_light_step<Cfg>(sc, ns, k, stk);
+                            box_steps();
+                        }
                     }
                 }
                 RT_STAMP(2);

@@ -16,6 +16,9 @@
  *   mode 0  W0: the product's stack walk (rt_walk_begin / rt_walk_step of rt_core.h), one stack entry per step.
  *   mode 7  W0b: W0 with four box-only steps behind every full step (rt_walk_box_step): a lane between boxes advances several nodes
  *           per execution of the rare kinds' code.  In the product for scenes with media (rt_kernel_plain.h: RT_SLICE_BOX_STEPS).
+ *   mode 8  W3: W0b with pair records for the BVH nodes that only steer (rt_core.h: rt_walkp_step): a steering node's record holds
+ *           both children's boxes in f32 rounded outward; a child whose box fails is never popped or fetched; gates (BVH nodes
+ *           directly above a primitive, a wrapper or a medium) keep their exact f64 test.  mode 9: the same without box-only steps.
  *   mode 3  W0q: W0 with the node records fetched by quads (four lanes share each 64-byte access) and transposed with DPP.
  *   mode 6  W2: the phased walk of rt_walk2.h -- W1's two phases for EVERY scene (wrappers, media, rects, nested BVHs), inner boxes
  *           in f32 rounded outward; what the product's stack-walk kernels are to run.
@@ -35,6 +38,7 @@
 #include "rt1w.h"
 #include "rt_kernel_sorted.h" /* rt_core.h, LdsStack, lane_prefix */
 #include "rt_walk2.h"
+#include "rt_pairs_build.h"
 #include "scene.h"
 #include "walk_lab.h"
 
@@ -147,6 +151,65 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, cons
 #pragma unroll
                 for (int extra = 0; extra < BOXSTEPS; ++extra)
                     if (between_boxes && !rt_walk_done(k, stk)) { between_boxes = rt_walk_box_step<Cfg>(ns, k, stk); steps += between_boxes ? 1ull : 0ull; }
+            }
+            if (rt_walk_done(k, stk)) walking = false;
+        }
+        ++wave_steps;
+    }
+    if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = 0u; out[mine] = h; }
+    if (stats) {
+        atomicAdd(&stats[0], steps);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&stats[1], wave_steps);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------- W3 -- */
+
+/* W3: the one-entry-per-step walk with PAIR RECORDS for the BVH nodes that only steer (rt_core.h: rt_walkp_step; `sc.nodes` is the
+ * patched copy, rt_pairs_build.h) and BOXSTEPS box-only steps behind every full step */
+template <class Cfg, int BOXSTEPS>
+__global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w3(RtSceneView sc, const RtPairRec* __restrict__ pairs, const LabRay* __restrict__ rays, unsigned long long n,
+                                                            LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
+                                                            unsigned long long* stats) {
+    __shared__ uint32_t stack_mem[RT_STACK_CAP * RT_BLOCK];
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    RtGlobalNodes ns{sc.nodes};
+    RtWalk k;
+    RtRng rng = rt_rng_make(0u, 0u, 0u, 0u, RT_DOMAIN_RENDER);
+    unsigned long long mine = ~0ull;
+    bool walking = false, exhausted = false;
+    unsigned long long steps = 0, wave_steps = 0;
+    for (;;) {
+        const bool idle = !walking;
+        const unsigned long long idle_m = __ballot(idle && !exhausted);
+        const unsigned long long walk_m = __ballot(walking);
+        if ((uint32_t)__popcll(idle_m) >= refill_idle || walk_m == 0ull) {
+            if (idle && !exhausted) {
+                if (mine != ~0ull) { LabHit h; h.t = k.best_t; h.prim = k.best_prim; h.flags = 0u; out[mine] = h; mine = ~0ull; }
+            }
+            const unsigned long long idx = lab_fetch(idle && !exhausted, counter);
+            if (idle && !exhausted) {
+                if (idx < n) {
+                    const LabRay r = rays[idx];
+                    RtRay w; w.o = rt_v3(r.o[0], r.o[1], r.o[2]); w.d = rt_v3(r.d[0], r.d[1], r.d[2]); w.time = r.time;
+                    rng = rt_rng_make((uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u, RT_DOMAIN_RENDER);
+                    stk.sp = 0;
+                    rt_walk_begin(k, sc.root, w, 0.001, RT_INF, stk);
+                    mine = idx; walking = true;
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(walking) == 0ull) break;
+        if (walking) {
+            rt_walkp_step<Cfg, true>(sc, ns, pairs, k, rng, stk);
+            ++steps;
+            if constexpr (BOXSTEPS > 0) { 
+                bool between_boxes = true;
+#pragma unroll
+                for (int extra = 0; extra < BOXSTEPS; ++extra)
+                    if (between_boxes && !rt_walk_done(k, stk)) { between_boxes = rt_walkp_box_step<Cfg>(ns, pairs, k, stk); steps += between_boxes ? 1ull : 0ull; }
             }
             if (rt_walk_done(k, stk)) walking = false;
         }
@@ -654,6 +717,10 @@ struct rt1w_lab {
     LabPNode* d_inner = nullptr; LabGroup* d_groups = nullptr; LabPNode32* d_inner32 = nullptr;
     LabW1Scene w1{};
     uint32_t n_inner = 0, n_groups = 0, stack_need = 0;
+    /* W3 */
+    RtNode* d_w3_nodes = nullptr; RtPairRec* d_w3_pairs = nullptr;
+    RtSceneView w3_view{};
+    uint32_t n_w3_pairs = 0;
     /* W2 */
     RtW2Inner* d_w2_inner = nullptr; uint32_t* d_w2_wref = nullptr;
     RtW2View w2{};
@@ -796,6 +863,16 @@ int rt1w_lab_create(rt1w_context* c, const rt1w_scene* s, rt1w_lab** out) {
         l->w2_ok = s->stack_need + 2u <= (uint32_t)RT_W2_STACK;
         l->stack_need = s->stack_need;
     }
+    {
+        std::vector<RtNode> patched(s->flat_nodes);
+        std::vector<RtPairRec> pairs;
+        rt_pairs_build(patched, pairs);
+        patched.push_back(RtNode()); /* the spare record behind the array (scene.cpp) */
+        if (pairs.empty()) pairs.push_back(RtPairRec());
+        if (!lab_upload(&l->d_w3_nodes, patched) || !lab_upload(&l->d_w3_pairs, pairs)) { rt1w_lab_destroy(l); return RT1W_ERR_DEVICE; }
+        l->w3_view = l->view; l->w3_view.nodes = l->d_w3_nodes;
+        l->n_w3_pairs = (uint32_t)pairs.size();
+    }
     *out = l;
     return RT1W_OK;
 }
@@ -808,6 +885,8 @@ void rt1w_lab_destroy(rt1w_lab* l) {
     if (l->d_inner) (void)hipFree(l->d_inner);
     if (l->d_groups) (void)hipFree(l->d_groups);
     if (l->d_inner32) (void)hipFree(l->d_inner32);
+    if (l->d_w3_nodes) (void)hipFree(l->d_w3_nodes);
+    if (l->d_w3_pairs) (void)hipFree(l->d_w3_pairs);
     if (l->d_w2_inner) (void)hipFree(l->d_w2_inner);
     if (l->d_w2_wref) (void)hipFree(l->d_w2_wref);
     if (l->ev0) (void)hipEventDestroy(l->ev0);
@@ -912,14 +991,16 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 6 && !l->w2_ok) { rt1w::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 7) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (mode < 0 || mode > 9) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
     const uint32_t box_steps = params && params[3] ? params[3] : 1u;
     int per_cu = 0;
     const void* fn = nullptr;
-    if (mode == 7) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4> : (const void*)lab_trace_w0<RtCfgV2, 4>);
+    if (mode == 8) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 4> : (const void*)lab_trace_w3<RtCfgV2, 4>);
+    else if (mode == 9) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 0> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 0> : (const void*)lab_trace_w3<RtCfgV2, 0>);
+    else if (mode == 7) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4> : (const void*)lab_trace_w0<RtCfgV2, 4>);
     else if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
     else if (mode == 3) fn = l->variant == 5 ? (const void*)lab_trace_w0q<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0q<RtCfgV3> : (const void*)lab_trace_w0q<RtCfgV2>);
     else if (mode == 6) fn = l->variant == 5 ? (const void*)lab_trace_w2<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w2<RtCfgV3> : (const void*)lab_trace_w2<RtCfgV2>);
@@ -934,7 +1015,12 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     for (int rep = 0; rep < (repeats > 0 ? repeats : 1); ++rep) {
         (void)hipMemsetAsync(l->d_counter, 0, 16 * sizeof(unsigned long long), l->stream);
         (void)hipEventRecord(l->ev0, l->stream);
-        if (mode == 7) {
+        if (mode == 8 || mode == 9) {
+#define LAB_W3(CFG, BS) hipLaunchKernelGGL((lab_trace_w3<CFG, BS>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->w3_view, l->d_w3_pairs, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1)
+            if (mode == 8) { if (l->variant == 5) LAB_W3(RtCfgV5, 4); else if (l->variant == 3) LAB_W3(RtCfgV3, 4); else LAB_W3(RtCfgV2, 4); }
+            else { if (l->variant == 5) LAB_W3(RtCfgV5, 0); else if (l->variant == 3) LAB_W3(RtCfgV3, 0); else LAB_W3(RtCfgV2, 0); }
+#undef LAB_W3
+        } else if (mode == 7) {
             if (l->variant == 5) hipLaunchKernelGGL((lab_trace_w0<RtCfgV5, 4>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL((lab_trace_w0<RtCfgV3, 4>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else hipLaunchKernelGGL((lab_trace_w0<RtCfgV2, 4>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);

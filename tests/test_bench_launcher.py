@@ -65,3 +65,30 @@ def test_launcher_parent_never_touches_the_gpu_stack():
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 0, p.stderr.decode()
     assert "MODS False False" in p.stdout.decode()
+
+
+def test_stored_pmc_is_attached_only_to_the_kernel_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic / valu_lane_issue_frac come from a stored rocprofv3 --pmc measurement (profiles/pmc_summary.json): it must
+    name the same kernel, the same specialisation key and the same kernel source text as the run it is attached to"""
+    sys.path.insert(0, ROOT)
+    import bench
+    ident = bench.kernel_sources_id()
+    assert ident and len(ident) == 12
+    (tmp_path / "profiles").mkdir()
+    ent = {"kernel": "rt_jit_sorted", "specialise_key": "abc", "kernel_sources": ident, "spp_of_the_traffic_figure": 1000,
+           "valu_lane_issue_frac": 0.4, "hbm_bytes_per_launch": 7}
+    (tmp_path / "profiles" / "pmc_summary.json").write_text(json.dumps({"c3": ent, "c4": dict(ent, kernel_sources="0" * 12)}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_id", lambda: ident)
+    assert bench.stored_pmc("c3", "rt_jit_sorted", "abc")["matches_this_run"] is True
+    assert bench.stored_pmc("c3", "rt_jit_sorted", "other key")["matches_this_run"] is False
+    assert bench.stored_pmc("c3", "rt_render_kernel<V0>", "abc")["matches_this_run"] is False
+    assert bench.stored_pmc("c4", "rt_jit_sorted", "abc")["matches_this_run"] is False    # measured on other kernel sources
+    assert bench.stored_pmc("c2", "rt_jit_sorted", "abc") is None
+    st = {"segments": 1000, "sorted": 4, "variant": 0}
+    r = bench.roofline_block("c3", st, 1.0, 100, "abc", spp=1000)
+    assert r["valu_lane_issue_frac"] == 0.4 and r["traffic"] == 7
+    r = bench.roofline_block("c3", st, 1.0, 100, "abc", spp=10)                            # another spp: no traffic figure
+    assert r["valu_lane_issue_frac"] == 0.4 and r["traffic"] is None
+    r = bench.roofline_block("c4", st, 1.0, 100, "abc", spp=1000)
+    assert r["valu_lane_issue_frac"] is None and r["traffic"] is None

@@ -43,6 +43,7 @@ for wl, spp in (("c3", 1000), ("c2", 500), ("c4", 400)):
     fetch_kb, write_kb = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
     out[wl] = {"kernel": kern, "specialise_key": (line.get("config", {}).get("specialise") or {}).get("key") if kern == "rt_jit_sorted" else None,
                "spp_of_the_traffic_figure": spp, "commit": line.get("config", {}).get("commit"),
+               "kernel_sources": line.get("config", {}).get("kernel_sources"),
                "valu_busy_frac": round(busy, 4), "lane_utilisation": round(lanes, 4), "valu_lane_issue_frac": round(busy * lanes, 4),
                "wave_cycles_waiting_frac": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 4),
                "SQ_INSTS_VALU_per_launch": m["SQ_INSTS_VALU"], "SQ_INSTS_SALU_per_launch": m["SQ_INSTS_SALU"],
