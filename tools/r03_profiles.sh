@@ -15,5 +15,6 @@ timeout -k 10 300 python3 bench.py --gpus 2 --all-ranks-on-device 0 --check-fram
 timeout -k 10 300 python3 bench.py --gpus 2 --all-ranks-on-device 0 --check-frame --steps 2 --workload c4 --spp 100 > $O/bench_2rank_c4.json 2> $O/bench_2rank_c4.err
 timeout -k 10 300 python3 bench.py --workload c2 --steps 3 > $O/bench_c2.json 2> $O/bench_c2.err
 echo "== stored PMC"; tools/bench_pmc.sh > $O/bench_pmc.log 2>&1; cp gpurun_out/bench_pmc/pmc_summary.json $O/ 2>/dev/null
+echo "== full sizes"; timeout -k 10 300 python3 tools/full_size.py C2 C4 C5 > $O/full_size.txt 2>&1
 echo "== configs"; timeout -k 10 500 python3 tools/configs_bench.py > $O/configs.txt 2>&1
 find $O -name "*kernel_stats.csv" | head; echo done
