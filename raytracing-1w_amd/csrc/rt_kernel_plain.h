@@ -37,6 +37,8 @@ struct LdsStack16 {
     __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); ++sp; }
     __device__ __forceinline__ void poke(int above, uint32_t v) { base[(sp + above) * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); }
     __device__ __forceinline__ uint32_t pop() { --sp; uint32_t x = base[sp * RT_BLOCK]; return (x & 0x7FFFu) | ((x & 0x8000u) ? RT_POP_FLAG : 0u); }
+    __device__ __forceinline__ uint32_t at(int i) const { uint32_t x = base[i * RT_BLOCK]; return (x & 0x7FFFu) | ((x & 0x8000u) ? RT_POP_FLAG : 0u); }
+    __device__ __forceinline__ void put(int i, uint32_t v) { base[i * RT_BLOCK] = (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); }
 };
 /* hot halves of all nodes copied into LDS once per workgroup (scenes of <= RT_LDS_NODE_CAP nodes): the
  * stack walk's dependent node fetches then cost LDS latency instead of L2/HBM latency */
@@ -55,8 +57,11 @@ struct LdsNodes {
 #ifndef RT_SLICE_PRIM_STEPS
 #define RT_SLICE_PRIM_STEPS 0 /* a primitive-only step + n more box steps behind the box steps: measured 247-249 against 252 Mpaths/s, off */
 #endif
+#ifndef RT_SLICE_BOX_RUN
+#define RT_SLICE_BOX_RUN 1 /* the box-only steps keep the top of the stack in a register (rt_kernel_sorted.h: rt_walk_box_run): final_scene +3 % */
+#endif
 #ifndef RT_SLICE_HEAVY_EVERY
-#define RT_SLICE_HEAVY_EVERY 1 /* n > 1: only every n-th full step of a media kernel takes ConstantMedium entries (rt_walk_light_step in between) */
+#define RT_SLICE_HEAVY_EVERY 2 /* only every second full step of a media kernel takes ConstantMedium entries (rt_walk_light_step in between): +2 % */
 #endif
 #ifndef RT_SLICE_BOX_MIN_LANES
 #define RT_SLICE_BOX_MIN_LANES 0
@@ -278,43 +283,41 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 RT_STAMP(7); /* bucket 7 here: rebuilding the walk's rays */
                 const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
                 const uint32_t stop_at = lanes_here > (uint32_t)RT_SLICE_IDLE(Cfg) ? lanes_here - (uint32_t)RT_SLICE_IDLE(Cfg) : 0u;
-                auto box_steps = [&]() {
-                    /* box-only steps on the same vote (rt_walk_box_step) */
-                    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {
-                        bool between_boxes = true; /* until the lane's next entry is something else: it then waits for the next full step */
-                        for (int extra = 0; extra < RT_SLICE_BOX_STEPS(Cfg); ++extra) {
-                            const bool go = between_boxes && !rt_walk_done(k, stk);
-                            if (RT_SLICE_BOX_MIN_LANES > 0 && (uint32_t)__popcll(__ballot(go)) < (uint32_t)RT_SLICE_BOX_MIN_LANES) break; /* too few lanes still between boxes */
-                            if (go) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);
-                        }
-#if RT_SLICE_PRIM_STEPS
-                        /* then one primitive-only step and more box steps behind it */
-                        if (!rt_walk_done(k, stk)) between_boxes = rt_walk_prim_step<Cfg>(sc, ns, k, stk) || between_boxes;
-#pragma unroll
-                        for (int extra = 0; extra < RT_SLICE_PRIM_STEPS; ++extra)
-                            if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);
-#endif
-                    }
-                };
-                for (bool stop = false; !stop;) {
+/* box-only steps on the same vote (rt_walk_box_step; RT_SLICE_BOX_RUN: the same steps with the top of the stack in a register).  A macro,
+ * not a lambda: wrapped in one, the same statements compiled to a kernel 13 % slower on final_scene (register allocation). */
+#define RT_SLICE_BOX_STEPS_HERE()                                                                                                   \
+    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN) {                                                                \
+        rt_walk_box_run<Cfg, RT_SLICE_BOX_STEPS(Cfg)>(ns, k, stk);                                                                  \
+    } else if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {                                                                             \
+        bool between_boxes = true; /* until the lane's next entry is something else: it then waits for the next full step */       \
+        for (int extra = 0; extra < RT_SLICE_BOX_STEPS(Cfg); ++extra) {                                                             \
+            const bool go = between_boxes && !rt_walk_done(k, stk);                                                                 \
+            if (RT_SLICE_BOX_MIN_LANES > 0 && (uint32_t)__popcll(__ballot(go)) < (uint32_t)RT_SLICE_BOX_MIN_LANES) break;           \
+            if (go) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);                                                              \
+        }                                                                                                                           \
+        if constexpr (RT_SLICE_PRIM_STEPS > 0) { /* then one primitive-only step and more box steps behind it */                    \
+            if (!rt_walk_done(k, stk)) between_boxes = rt_walk_prim_step<Cfg>(sc, ns, k, stk) || between_boxes;                     \
+            for (int extra = 0; extra < RT_SLICE_PRIM_STEPS; ++extra)                                                               \
+                if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);                      \
+        }                                                                                                                           \
+    }
+                for (;;) {
                     const bool more = !rt_walk_done(k, stk);
                     if (__popcll(__ballot(more)) <= stop_at) break; /* wave-uniform: enough lanes are done (or all) */
                     if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
                     /* a second step on the same vote where a step is cheap (measured: random_scene +1.8 %; final_scene, whose steps
                      * can be a whole medium, -4 %) */
                     if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
-                    box_steps();
+                    RT_SLICE_BOX_STEPS_HERE()
                     if constexpr (Cfg::media && RT_SLICE_HEAVY_EVERY > 1) {
-                        /* then rounds whose full step leaves media alone (rt_walk_light_step) */
-#pragma unroll
-                        for (int r = 1; r < RT_SLICE_HEAVY_EVERY; ++r) {
-                            const bool more2 = !rt_walk_done(k, stk);
-                            if (__popcll(__ballot(more2)) <= stop_at) { stop = true; break; }
-                            if (more2) rt_walk_light_step<Cfg>(sc, ns, k, stk);
-                            box_steps();
-                        }
+                        /* then a round whose full step leaves media alone (rt_walk_light_step) */
+                        const bool more2 = !rt_walk_done(k, stk);
+                        if (__popcll(__ballot(more2)) <= stop_at) break;
+                        if (more2) rt_walk_light_step<Cfg>(sc, ns, k, stk);
+                        RT_SLICE_BOX_STEPS_HERE()
                     }
                 }
+#undef RT_SLICE_BOX_STEPS_HERE
                 RT_STAMP(2);
                 if (rt_walk_done(k, stk)) {
                     walking = false;

@@ -32,7 +32,47 @@ struct LdsStack {
     __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = v; ++sp; }
     __device__ __forceinline__ void poke(int above, uint32_t v) { base[(sp + above) * RT_BLOCK] = v; } /* write without moving the top */
     __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
+    __device__ __forceinline__ uint32_t at(int i) const { return base[i * RT_BLOCK]; } /* entry i, whatever the level */
+    __device__ __forceinline__ void put(int i, uint32_t v) { base[i * RT_BLOCK] = v; }
 };
+
+/* N box-only steps in a row (rt_core.h: rt_walk_box_step) with the TOP OF THE STACK IN A REGISTER: in the one-step form every step
+ * writes the children to LDS and the next step reads the top back -- an LDS round trip inside the chain pop -> fetch -> test -> push
+ * that paces the walk.  Here the entry below the top is requested together with the node record (it is needed only after a miss), a
+ * hit continues with the left child (the next node in pre-order) from the register, and the top goes back to LDS once, at the end.
+ * Same entries, same order: a lane stops at its first entry that is not a BVH node, as rt_walk_box_step does.  For walks whose
+ * stack starts at level 0 (the render kernels' outer walk).  Written without nested branches: the stores below the top that a lane
+ * does not need land in dead slots (its own top's slot, rewritten at the end; slot 0 of a finished lane). */
+template <class Cfg, int N, class NS, class Stack>
+__device__ __forceinline__ void rt_walk_box_run(const NS& ns, RtWalk& k, Stack& stk) {
+    int sp = stk.sp;
+    bool go = sp > 0;
+    uint32_t top = stk.at(sp > 0 ? sp - 1 : 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool node = go && !(Cfg::scope_depth > 0 && (top & RT_POP_FLAG));
+        const uint32_t under = stk.at(sp > 1 ? sp - 2 : 0);
+        const uint32_t e = node ? top : 0u;
+        const RtNodeHot nd = ns.hot(e);
+        const uint32_t km = nd.kind & RT_KIND_MASK;
+        const bool take = node && km <= RT_BVH1;
+        const bool two = km == RT_BVH2;
+        const bool hit = take && rt_walk_slab<Cfg, false>(k, nd);
+        uint32_t first = e + 1u, second = nd.b; /* left child = the next node in pre-order, then the right one: bvh.rs:38-47 */
+        if constexpr (Cfg::ordered) {
+            const uint32_t ord = (nd.kind >> RT_BVH_ORDER_SHIFT) & RT_BVH_ORDER_MASK;
+            const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
+            const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
+            if (two && ord != 0u && ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower))) { first = nd.b; second = e + 1u; }
+        }
+        stk.put(sp > 0 ? sp - 1 : 0, second); /* the top's own slot: the second child of a hit BVHChild::Two, dead otherwise */
+        sp += hit ? (two ? 1 : 0) : (take ? -1 : 0);
+        top = hit ? first : (take ? under : top);
+        go = take && sp > 0;
+    }
+    stk.put(sp > 0 ? sp - 1 : 0, top);
+    stk.sp = sp;
+}
 
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

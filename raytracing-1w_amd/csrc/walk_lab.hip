@@ -16,6 +16,7 @@
  *   mode 0  W0: the product's stack walk (rt_walk_begin / rt_walk_step of rt_core.h), one stack entry per step.
  *   mode 7  W0b: W0 with four box-only steps behind every full step (rt_walk_box_step): a lane between boxes advances several nodes
  *           per execution of the rare kinds' code.  In the product for scenes with media (rt_kernel_plain.h: RT_SLICE_BOX_STEPS).
+ *   mode 10 W0c: W0b with the top of the stack in a register during the box-only steps (rt_kernel_sorted.h: rt_walk_box_run).
  *   mode 8  W3: W0b with pair records for the BVH nodes that only steer (rt_core.h: rt_walkp_step): a steering node's record holds
  *           both children's boxes in f32 rounded outward; a child whose box fails is never popped or fetched; gates (BVH nodes
  *           directly above a primitive, a wrapper or a medium) keep their exact f64 test.  mode 9: the same without box-only steps.
@@ -108,7 +109,7 @@ __device__ __forceinline__ unsigned long long lab_fetch(bool want, unsigned long
 /* ------------------------------------------------------------------------------------------------- W0 -- */
 
 /* the product's walk, one entry per step; idle lanes refill once `refill_idle` of them wait (or nothing else can step) */
-template <class Cfg, int BOXSTEPS = 0>
+template <class Cfg, int BOXSTEPS = 0, bool RUN = false>
 __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, const LabRay* __restrict__ rays, unsigned long long n,
                                                             LabHit* __restrict__ out, unsigned long long* counter, uint32_t refill_idle,
                                                             unsigned long long* stats) {
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, cons
         if (walking) {
             rt_walk_step<Cfg, true>(sc, ns, k, rng, stk);
             ++steps;
-            if constexpr (BOXSTEPS > 0) { /* W0b: box-only steps behind the full step (rt_walk_box_step; what the render kernels of media scenes do) */
+            if constexpr (BOXSTEPS > 0 && RUN) { /* W0c: the same steps with the top of the stack in a register (rt_walk_box_run) */
+                rt_walk_box_run<Cfg, BOXSTEPS>(ns, k, stk);
+            } else if constexpr (BOXSTEPS > 0) { /* W0b: box-only steps behind the full step (rt_walk_box_step; what the render kernels of media scenes do) */
                 bool between_boxes = true;
 #pragma unroll
                 for (int extra = 0; extra < BOXSTEPS; ++extra)
@@ -991,14 +994,15 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 6 && !l->w2_ok) { rt1w::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 9) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (mode < 0 || mode > 10) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
     const uint32_t box_steps = params && params[3] ? params[3] : 1u;
     int per_cu = 0;
     const void* fn = nullptr;
-    if (mode == 8) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 4> : (const void*)lab_trace_w3<RtCfgV2, 4>);
+    if (mode == 10) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4, true> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4, true> : (const void*)lab_trace_w0<RtCfgV2, 4, true>);
+    else if (mode == 8) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 4> : (const void*)lab_trace_w3<RtCfgV2, 4>);
     else if (mode == 9) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 0> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 0> : (const void*)lab_trace_w3<RtCfgV2, 0>);
     else if (mode == 7) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4> : (const void*)lab_trace_w0<RtCfgV2, 4>);
     else if (mode == 0) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3> : (const void*)lab_trace_w0<RtCfgV2>);
@@ -1015,7 +1019,11 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     for (int rep = 0; rep < (repeats > 0 ? repeats : 1); ++rep) {
         (void)hipMemsetAsync(l->d_counter, 0, 16 * sizeof(unsigned long long), l->stream);
         (void)hipEventRecord(l->ev0, l->stream);
-        if (mode == 8 || mode == 9) {
+        if (mode == 10) {
+            if (l->variant == 5) hipLaunchKernelGGL((lab_trace_w0<RtCfgV5, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else if (l->variant == 3) hipLaunchKernelGGL((lab_trace_w0<RtCfgV3, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+            else hipLaunchKernelGGL((lab_trace_w0<RtCfgV2, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+        } else if (mode == 8 || mode == 9) {
 #define LAB_W3(CFG, BS) hipLaunchKernelGGL((lab_trace_w3<CFG, BS>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->w3_view, l->d_w3_pairs, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1)
             if (mode == 8) { if (l->variant == 5) LAB_W3(RtCfgV5, 4); else if (l->variant == 3) LAB_W3(RtCfgV3, 4); else LAB_W3(RtCfgV2, 4); }
             else { if (l->variant == 5) LAB_W3(RtCfgV5, 0); else if (l->variant == 3) LAB_W3(RtCfgV3, 0); else LAB_W3(RtCfgV2, 0); }

@@ -40,6 +40,7 @@ def test_walk_candidates_answer_like_the_product_walk(rt, gpu_ctx_factory):
         assert wl.same_hits(base, lab.trace(7, repeats=1))           # box-only steps behind the full step
         assert wl.same_hits(base, lab.trace(8, repeats=1))           # pair records for the steering BVH nodes (+ box-only steps)
         assert wl.same_hits(base, lab.trace(9, repeats=1))
+        assert wl.same_hits(base, lab.trace(10, repeats=1))          # box-only steps with the top of the stack in a register
         try:
             w2 = lab.trace(6, repeats=1, votes=24)                   # the phased walk, every scene
             assert wl.same_hits(base, w2), sc.info()

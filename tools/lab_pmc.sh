@@ -20,9 +20,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"lab_trace_(w0q|w0|w2|w1<[^>]*>)", r["Kernel_Name"])
+        m = re.search(r"lab_trace_(w0q|w0|w2|w3<[^>]*>|w1<[^>]*>)", r["Kernel_Name"])
         k = ("lab_trace_" + m.group(1).replace(" ", "")) if m else None
         if k == "lab_trace_w0" and re.search(r"lab_trace_w0<.*, 4>", r["Kernel_Name"]): k = "lab_trace_w0b"
+        if k and k.startswith("lab_trace_w3"): k = "lab_trace_w3" + ("" if re.search(r"lab_trace_w3<.*, 4>", r["Kernel_Name"]) else "_no_box_steps")
         if k:
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 with open("$OUT/summary.txt", "w") as o:

@@ -107,7 +107,7 @@ def main():
               f"{base['stats'][1] * 64 / n:7.1f}", end="", flush=True)
         wb = min((lab.trace(7, refill=rf) for rf in (32, 48)), key=lambda r: r["ms"])
         print(f" | W0b (4 box-only steps) {n / wb['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / wb['ms']:.2f}x) wave-steps/64 rays {wb['stats'][1] * 64 / n:6.1f} hits equal W0: {same_hits(base, wb)}", end="", flush=True)
-        for mode, label in ((8, "W3 (pair records + 4 box-only steps)"), (9, "W3 without box-only steps")):
+        for mode, label in ((10, "W0c (W0b, top of the stack in a register)"), (8, "W3 (pair records + 4 box-only steps)"), (9, "W3 without box-only steps")):
             w3 = min((lab.trace(mode, refill=rf) for rf in (32, 48)), key=lambda r: r["ms"])
             print(f" | {label} {n / w3['ms'] / 1e3:8.1f} Mrays/s ({base['ms'] / w3['ms']:.2f}x) steps/ray {w3['stats'][0] / n:5.1f} wave-steps/64 rays {w3['stats'][1] * 64 / n:6.1f} hits equal W0: {same_hits(base, w3)}", end="", flush=True)
         q = min((lab.trace(3, refill=rf) for rf in ((16, 32, 48, 60) if sweep else (32, 48))), key=lambda r: r["ms"])
