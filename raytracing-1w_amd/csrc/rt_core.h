@@ -530,6 +530,8 @@ RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_
              * test -- run the two tests (sphere.rs:31-48 with (-inf, inf), then (t1 + 0.0001, inf)) without the walk around them */
             const RtV3 c = rt_v3(bn.d[0], bn.d[1], bn.d[2]);
             both = rt_sphere_root(c, bn.d[3], br.o, br.d, -RT_INF, RT_INF, t1) && rt_sphere_root(c, bn.d[3], br.o, br.d, t1 + RT_R(0.0001), RT_INF, t2);
+        } else if constexpr (Cfg::sphere_media) {
+            both = false; (void)p_; (void)s_; /* not reached: the host gives these kernels only scenes without such a medium (RtCfgSphereMedia) */
         } else {
             both = rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_, &k.inv) &&
                    rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + RT_R(0.0001), RT_INF, rng, stk, t2, p_, s_, &k.inv);

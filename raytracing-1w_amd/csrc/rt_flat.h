@@ -172,6 +172,15 @@ struct RtCfg {
     static constexpr bool tex = TEX_;         /* scene has non-solid textures (checker/noise/image) */
     static constexpr bool msphere = MSPHERE_; /* scene has MovingSphere primitives */
     static constexpr bool sweep = SWEEP_;     /* stackless pre-order sweep instead of the LDS stack */
+    static constexpr bool sphere_media = false; /* see RtCfgSphereMedia */
+};
+/* A variant for scenes whose every ConstantMedium is bounded by a bare Sphere (final_scene: main.rs:730-752): the kernel then
+ * carries the two sphere roots of constant_medium.rs:62-69 only, not the two complete boundary WALKS a general boundary needs --
+ * 1400 instructions and two more walk states that the stack walk's loop otherwise holds for nothing (final_scene +5 %).  Chosen
+ * by the host from the flattened scene (context.hip); the same arithmetic on the path that runs, so the same bits. */
+template <class Base>
+struct RtCfgSphereMedia : Base {
+    static constexpr bool sphere_media = true;
 };
 /* the variants that are built (host picks the cheapest one that covers the scene) */
 typedef RtCfg<false, false, false, true, 2> RtCfgV0; /* small scene, solid colours only, no media, no moving spheres (Cornell box) */

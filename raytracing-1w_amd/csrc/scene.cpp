@@ -723,6 +723,10 @@ static int flatten_scene(rt1w_scene* s) {
     for (const RtTexture& t : s->textures) if (t.kind != RT_TEX_SOLID) s->has_tex = true;
     s->has_msphere = false;
     for (const RtNode& n : s->flat_nodes) if ((n.kind & RT_KIND_MASK) == RT_MSPHERE) s->has_msphere = true;
+    s->media_bare_spheres = s->has_media;
+    for (size_t i = 0; i < s->flat_nodes.size(); ++i) /* a medium's boundary is the next node in pre-order (rt_flat.h) */
+        if ((s->flat_nodes[i].kind & RT_KIND_MASK) == RT_MEDIUM && (i + 1 >= s->flat_nodes.size() || (s->flat_nodes[i + 1].kind & RT_KIND_MASK) != RT_SPHERE))
+            s->media_bare_spheres = false;
     if (s->stack_need > RT_STACK_CAP) {
         set_error("scene needs a deeper traversal stack than RT_STACK_CAP");
         s->flat_nodes.clear();

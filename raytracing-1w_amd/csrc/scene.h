@@ -55,6 +55,7 @@ struct rt1w_scene {
     uint32_t flat_root = RT_NONE;
     uint32_t stack_need = 0, scope_depth = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
+    bool media_bare_spheres = false; /* every ConstantMedium's boundary is a bare Sphere node (the kernels of RtCfgSphereMedia) */
     uint32_t walk_order = 0; /* RT1W_WALK_* */
     uint32_t walk_annotated = 0; /* BVH nodes that carry an order annotation (0: the plain kernels serve) */
     uint32_t bvh_build = 0;  /* RT1W_BVH_* */

@@ -721,6 +721,38 @@ def test_pair_walk_of_sphere_scenes_is_bit_identical(rt, gpu_ctx_factory):
     assert not (st["sorted"] & 128)
 
 
+def test_sphere_media_kernels_are_bit_identical(rt, gpu_ctx_factory):
+    """Scenes whose every ConstantMedium is bounded by a bare Sphere (final_scene, main.rs:730-752) run stack-walk kernels built
+    without the general boundary walks (rt_flat.h: RtCfgSphereMedia; stats.sorted bit 8).  Same frame as the general kernel
+    (RT1W_CLASSIC_WALK) and as the CPU build of the core, on the reference's tree, the SAH tree and with the near-far order (V4);
+    a scene with a medium inside a box (not a bare sphere) must keep the general kernel."""
+    for sah, near_far in ((False, False), (True, False), (True, True)):
+        sc = rt.Scene.reference(7, build_seed=1)
+        if sah:
+            sc.set_bvh_build(True)
+        if near_far:
+            sc.set_walk_order(True)
+        ctx = gpu_ctx_factory(sc)
+        for W, H, spp in ((64, 64, 6), (320, 320, 3)):
+            a, sa = ctx.render(W, H, spp)
+            b, sb = ctx.render(W, H, spp, classic_walk=True)
+            assert sa["sorted"] & 256 and not (sb["sorted"] & 256), (sa["sorted"], sb["sorted"])
+            assert sa["variant"] == sb["variant"] == (4 if near_far else 3)
+            assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, near_far, W, H, spp)
+        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=rt.default_chunk(64, 64, 6))
+        a, sa = ctx.render(64, 64, 6)
+        assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), (sah, near_far)
+        ctx.close()
+    # media bounded by boxes under wrappers (cornel_smoke, main.rs:528-546) keep the general kernel, also when the stack walk is forced
+    sc = rt.Scene.reference(6, build_seed=1)
+    ctx = gpu_ctx_factory(sc)
+    a, sa = ctx.render(48, 48, 4, variant=3)
+    assert sa["variant"] == 3 and not (sa["sorted"] & 256)
+    cpu, sc_ = orc.flat_render(sc, 48, 48, 4, chunk=rt.default_chunk(48, 48, 4))
+    assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True)
+    ctx.close()
+
+
 def test_precompiled_kernels_load_on_a_host_without_the_runtime_compiler(rt):
     """A host that cannot compile (no libhiprtc: RT1W_NO_HIPRTC hides it) still runs the scene-specialised kernels the build
     precompiled under <package>/kernels -- their key no longer contains the host's compiler id (round-2 advice)."""
