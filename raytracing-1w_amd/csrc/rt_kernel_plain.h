@@ -57,6 +57,9 @@ struct LdsNodes {
 #ifndef RT_SLICE_PRIM_STEPS
 #define RT_SLICE_PRIM_STEPS 0 /* a primitive-only step + n more box steps behind the box steps: measured 247-249 against 252 Mpaths/s, off */
 #endif
+#ifndef RT_SLICE_BOX_RUN_ORDERED
+#define RT_SLICE_BOX_RUN_ORDERED 0 /* the near-far kernels (V4) keep the one-step form: the register form measured 233 against 257 Mpaths/s there (tools/v4_ab.py) */
+#endif
 #ifndef RT_SLICE_BOX_RUN
 #define RT_SLICE_BOX_RUN 1 /* the box-only steps keep the top of the stack in a register (rt_kernel_sorted.h: rt_walk_box_run): final_scene +3 % */
 #endif
@@ -286,7 +289,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
 /* box-only steps on the same vote (rt_walk_box_step; RT_SLICE_BOX_RUN: the same steps with the top of the stack in a register).  A macro,
  * not a lambda: wrapped in one, the same statements compiled to a kernel 13 % slower on final_scene (register allocation). */
 #define RT_SLICE_BOX_STEPS_HERE()                                                                                                   \
-    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN) {                                                                \
+    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) {                 \
         rt_walk_box_run<Cfg, RT_SLICE_BOX_STEPS(Cfg)>(ns, k, stk);                                                                  \
     } else if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {                                                                             \
         bool between_boxes = true; /* until the lane's next entry is something else: it then waits for the next full step */       \
