@@ -166,6 +166,182 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0(RtSceneView sc, cons
     }
 }
 
+/* ------------------------------------------------------------------------------------------------- W4 -- */
+
+/* W4: the product's steps (one full step + BOXSTEPS box-only steps per round, as W0c) with the walks REGROUPED ACROSS THE FOUR WAVES of
+ * a workgroup by the kind of their next entry.  final_scene's walk is bound by kind divergence (finding 2): nearly
+ * every full step of a wave runs the sphere, rect, wrapper, exit and medium code for two or three lanes each.  Here the walk state of
+ * the workgroup's 256 rays lives in LDS (11 qwords + 7 dwords per slot, the per-slot stack next to it), and before every round the
+ * slots are counting-sorted by (inside a wrapper?, kind of the top entry): lane i of the workgroup then takes the i-th slot of that
+ * order, loads what the step needs, steps, and stores what changed (closest hit, scope, stack level, draws).  A wave then holds one or
+ * two kinds.  Per ray nothing changes -- the same entries in the same order with the same operands, whichever lane executes them -- so
+ * the hits are W0's bit for bit.  A ConstantMedium's draw comes from the ray's own counter-based stream: the slot carries the number of
+ * draws taken so far and the lane at the medium regenerates the generator at that position (rt_rng_rewind).
+ * Slices as in the render kernels, per workgroup: once `slice_idle` of the slice's walks have ended every lane goes home to its own
+ * slot, writes a finished walk's hit out and starts the next ray there. */
+#define LAB_W4_NODE_CAP 8192 /* node kinds as bytes in LDS */
+#define LAB_W4_STACK 24
+#define LAB_W4_DONE 15u
+struct LabStack16 { /* 16-bit entries (node index < 32768, wrapper-exit flag in bit 15), entry e of the slot at base[e * RT_BLOCK] */
+    uint16_t* base;
+    int sp;
+    __device__ __forceinline__ static uint16_t enc(uint32_t v) { return (uint16_t)((v & 0x7FFFu) | ((v & RT_POP_FLAG) ? 0x8000u : 0u)); }
+    __device__ __forceinline__ static uint32_t dec(uint32_t x) { return (x & 0x7FFFu) | ((x & 0x8000u) ? RT_POP_FLAG : 0u); }
+    __device__ __forceinline__ void push(uint32_t v) { base[sp * RT_BLOCK] = enc(v); ++sp; }
+    __device__ __forceinline__ void poke(int above, uint32_t v) { base[(sp + above) * RT_BLOCK] = enc(v); }
+    __device__ __forceinline__ uint32_t pop() { --sp; return dec(base[sp * RT_BLOCK]); }
+    __device__ __forceinline__ uint32_t at(int i) const { return dec(base[i * RT_BLOCK]); }
+    __device__ __forceinline__ void put(int i, uint32_t v) { base[i * RT_BLOCK] = enc(v); }
+};
+/* inclusive prefix sum over the 64 lanes of a wave (row shifts + row broadcasts, the rocPRIM pattern) */
+__device__ __forceinline__ uint32_t lab_wave_scan(uint32_t v, uint32_t lane) {
+    const uint32_t rl = lane & 15u;
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x111, 0xf, 0xf, false); if (rl >= 1u) v += t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x112, 0xf, 0xf, false); if (rl >= 2u) v += t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x114, 0xf, 0xf, false); if (rl >= 4u) v += t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x118, 0xf, 0xf, false); if (rl >= 8u) v += t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x142, 0xf, 0xf, false); if ((lane & 31u) >= 16u) v += t; /* row_bcast:15 */
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x143, 0xf, 0xf, false); if (lane >= 32u) v += t;         /* row_bcast:31 */
+    return v;
+}
+template <class Cfg, int BOXSTEPS>
+__global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w4(RtSceneView sc, const uint8_t* __restrict__ cls_tab, const LabRay* __restrict__ rays, unsigned long long n,
+                                                            LabHit* __restrict__ out, unsigned long long* counter, uint32_t slice_idle,
+                                                            unsigned long long* stats) {
+    __shared__ double s64[11 * RT_BLOCK];   /* w.o xyz, w.d xyz, 1/w.d xyz, time, closest t */
+    __shared__ uint32_t s32[7 * RT_BLOCK];  /* scope, closest primitive, its scope, stack level, draws taken, ray index lo / hi */
+    __shared__ uint16_t stack_mem[LAB_W4_STACK * RT_BLOCK];
+    __shared__ uint8_t cls_lds[LAB_W4_NODE_CAP];
+    __shared__ uint16_t perm[RT_BLOCK];
+    __shared__ uint32_t cnt[64]; /* [key][wave] */
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < sc.n_nodes && i < (uint32_t)LAB_W4_NODE_CAP; i += RT_BLOCK) cls_lds[i] = cls_tab[i];
+    RtGlobalNodes ns{sc.nodes};
+    unsigned long long mine = ~0ull;
+    bool exhausted = false;
+    unsigned long long steps = 0, rounds = 0, slices = 0;
+    s32[3 * RT_BLOCK + tid] = 0u;
+    __syncthreads();
+    /* key of a slot: what its top entry is (bit 3: inside a wrapper, where the step rebuilds the wrapper's ray first) */
+    auto slot_key = [&](uint32_t slot, uint32_t sp, uint32_t scope) -> uint32_t {
+        if (sp == 0u) return LAB_W4_DONE;
+        const uint32_t x = stack_mem[(sp - 1u) * RT_BLOCK + slot];
+        if (x & 0x8000u) return 14u;
+        return (uint32_t)cls_lds[x] | (scope != RT_NONE ? 8u : 0u);
+    };
+    for (;;) { /* ---- a slice: home, then rounds ---- */
+        {
+            const bool idle = s32[3 * RT_BLOCK + tid] == 0u;
+            if (idle && mine != ~0ull) {
+                LabHit h; h.t = s64[10 * RT_BLOCK + tid]; h.prim = s32[1 * RT_BLOCK + tid]; h.flags = 0u; out[mine] = h; mine = ~0ull;
+            }
+            const unsigned long long idx = lab_fetch(idle && !exhausted, counter);
+            if (idle && !exhausted) {
+                if (idx < n) {
+                    const LabRay r = rays[idx];
+                    const RtV3 inv = rt_inv3(rt_v3(r.d[0], r.d[1], r.d[2]));
+                    s64[0 * RT_BLOCK + tid] = r.o[0]; s64[1 * RT_BLOCK + tid] = r.o[1]; s64[2 * RT_BLOCK + tid] = r.o[2];
+                    s64[3 * RT_BLOCK + tid] = r.d[0]; s64[4 * RT_BLOCK + tid] = r.d[1]; s64[5 * RT_BLOCK + tid] = r.d[2];
+                    s64[6 * RT_BLOCK + tid] = inv.x; s64[7 * RT_BLOCK + tid] = inv.y; s64[8 * RT_BLOCK + tid] = inv.z;
+                    s64[9 * RT_BLOCK + tid] = r.time; s64[10 * RT_BLOCK + tid] = RT_INF;
+                    s32[0 * RT_BLOCK + tid] = RT_NONE; s32[1 * RT_BLOCK + tid] = RT_NONE; s32[2 * RT_BLOCK + tid] = RT_NONE;
+                    s32[3 * RT_BLOCK + tid] = 1u; s32[4 * RT_BLOCK + tid] = 0u;
+                    s32[5 * RT_BLOCK + tid] = (uint32_t)idx; s32[6 * RT_BLOCK + tid] = (uint32_t)(idx >> 32);
+                    stack_mem[tid] = LabStack16::enc(sc.root);
+                    mine = idx;
+                } else exhausted = true;
+            }
+        }
+        uint32_t myslot = tid;
+        uint32_t key = slot_key(tid, s32[3 * RT_BLOCK + tid], s32[0 * RT_BLOCK + tid]);
+        uint32_t stop_at = 0u;
+        bool first = true, finished = false;
+        ++slices;
+        for (;;) { /* ---- a round: sort the slots by key, one full step + the box-only steps ---- */
+            /* rank among the lanes of this wave with the same key, and that key's count */
+            unsigned long long same = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long m = __ballot((key >> b) & 1u);
+                same &= ((key >> b) & 1u) ? m : ~m;
+            }
+            same &= __ballot(1);
+            const uint32_t rank = lane_prefix(same);
+            if (lane < 16u) cnt[lane * 4u + wave] = 0u;
+            if (rank == 0u) cnt[key * 4u + wave] = (uint32_t)__popcll(same);
+            __syncthreads();
+            const uint32_t c = cnt[lane];
+            const uint32_t incl = lab_wave_scan(c, lane);
+            const uint32_t excl = incl - c;
+            const uint32_t dest = (uint32_t)__shfl((int)excl, (int)(key * 4u + wave)) + rank;
+            const uint32_t active = (uint32_t)__builtin_amdgcn_readlane((int)excl, 60); /* slots whose walk is not over */
+            if (first) {
+                if (active == 0u) { finished = true; break; }
+                stop_at = active > slice_idle ? active - slice_idle : 0u;
+                first = false;
+            } else if (active <= stop_at) break;
+            perm[dest] = (uint16_t)myslot;
+            __syncthreads();
+            myslot = perm[tid];
+            ++rounds;
+            if (tid < active) {
+                const uint32_t sl = myslot;
+                RtWalk k;
+                k.w.o = rt_v3(s64[0 * RT_BLOCK + sl], s64[1 * RT_BLOCK + sl], s64[2 * RT_BLOCK + sl]);
+                k.w.d = rt_v3(s64[3 * RT_BLOCK + sl], s64[4 * RT_BLOCK + sl], s64[5 * RT_BLOCK + sl]);
+                k.inv_w = rt_v3(s64[6 * RT_BLOCK + sl], s64[7 * RT_BLOCK + sl], s64[8 * RT_BLOCK + sl]);
+                k.time = s64[9 * RT_BLOCK + sl]; k.best_t = s64[10 * RT_BLOCK + sl];
+                k.scope = s32[0 * RT_BLOCK + sl]; k.best_prim = s32[1 * RT_BLOCK + sl]; k.best_scope = s32[2 * RT_BLOCK + sl];
+                uint32_t ndraw = s32[4 * RT_BLOCK + sl];
+                k.t_min = 0.001; k.tmin_nan = false; k.base = 0;
+                LabStack16 stk; stk.base = stack_mem + sl; stk.sp = (int)s32[3 * RT_BLOCK + sl];
+                if (Cfg::scope_depth == 0 || k.scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
+                else {
+                    bool rotated;
+                    k.cur = rt_ray_in_scope_r(sc.nodes, k.scope, k.w, rotated);
+                    k.inv = k.inv_w;
+                    if (rotated) k.inv = rt_inv3(k.cur.d);
+                }
+                /* the full step (rt_walk_step), a medium's draw taken from the ray's own stream at the position the slot has reached */
+                {
+                    const uint32_t e = stk.pop();
+                    if (Cfg::scope_depth > 0 && (e & RT_POP_FLAG)) rt_walk_exit(sc, k, e);
+                    else {
+                        const RtNodeHot nd = ns.hot(e);
+                        const uint32_t km = nd.kind & RT_KIND_MASK;
+                        if (km <= RT_BVH1) rt_walk_box<Cfg, false>(k, e, nd, stk);
+                        else if (km <= RT_YZ) rt_walk_leaf<Cfg>(sc, k, e, nd);
+                        else if (Cfg::scope_depth > 0 && km <= RT_FLIP) rt_walk_wrap(k, e, nd, stk);
+                        else if (Cfg::media) {
+                            RtRng rng = rt_rng_make(s32[5 * RT_BLOCK + sl], s32[6 * RT_BLOCK + sl], 0u, 0u, RT_DOMAIN_RENDER);
+                            RtRngMark m; m.bv = 0u; m.left = (ndraw & 1u) ? 2u : 0u; m.blk = (ndraw + 1u) >> 1;
+                            rt_rng_rewind(rng, m);
+                            rt_walk_other<Cfg, true>(sc, ns, k, e, nd, rng, stk);
+                            ndraw = (4u * (rng.blk - rng.bv) - rng.left) >> 1;
+                        }
+                    }
+                    ++steps;
+                }
+                if constexpr (BOXSTEPS > 0) rt_walk_box_run<Cfg, BOXSTEPS>(ns, k, stk);
+                s64[10 * RT_BLOCK + sl] = k.best_t;
+                s32[0 * RT_BLOCK + sl] = k.scope; s32[1 * RT_BLOCK + sl] = k.best_prim; s32[2 * RT_BLOCK + sl] = k.best_scope;
+                s32[3 * RT_BLOCK + sl] = (uint32_t)stk.sp; s32[4 * RT_BLOCK + sl] = ndraw;
+                key = stk.sp >= LAB_W4_STACK - 2 ? LAB_W4_DONE /* cannot happen on a scene the host admitted; never walk past the slot's words */
+                                                 : slot_key(sl, (uint32_t)stk.sp, k.scope);
+                if (key == LAB_W4_DONE) s32[3 * RT_BLOCK + sl] = 0u;
+            } else key = LAB_W4_DONE;
+            if (rounds > (1ull << 26)) { finished = true; break; } /* safety net of the experiment: a grid that cannot drain must not exist */
+        }
+        if (finished) break;
+        __syncthreads(); /* the count table is written again at once by the next slice's first round */
+    }
+    if (stats) {
+        atomicAdd(&stats[0], steps);
+        if (lane == 0u) { atomicAdd(&stats[1], rounds); atomicAdd(&stats[2], slices); }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------- W3 -- */
 
 /* W3: the one-entry-per-step walk with PAIR RECORDS for the BVH nodes that only steer (rt_core.h: rt_walkp_step; `sc.nodes` is the
@@ -728,6 +904,8 @@ struct rt1w_lab {
     RtW2Inner* d_w2_inner = nullptr; uint32_t* d_w2_wref = nullptr;
     RtW2View w2{};
     bool w2_ok = false;
+    /* W4 */
+    uint8_t* d_w4_cls = nullptr; bool w4_ok = false, sphere_media = false; uint32_t n_nodes = 0;
 };
 
 namespace {
@@ -876,6 +1054,19 @@ int rt1w_lab_create(rt1w_context* c, const rt1w_scene* s, rt1w_lab** out) {
         l->w3_view = l->view; l->w3_view.nodes = l->d_w3_nodes;
         l->n_w3_pairs = (uint32_t)pairs.size();
     }
+    {
+        /* W4: the sort key of a node (0 BVH node, 1 sphere, 2 rect, 3 moving sphere, 4 wrapper, 5 medium) as one byte per node */
+        std::vector<uint8_t> cls(s->flat_nodes.size());
+        for (size_t i = 0; i < cls.size(); ++i) {
+            const uint32_t km = s->flat_nodes[i].kind & RT_KIND_MASK;
+            cls[i] = km <= RT_BVH1 ? 0 : km == RT_SPHERE ? 1 : km == RT_MSPHERE ? 3 : km <= RT_YZ ? 2 : km <= RT_FLIP ? 4 : 5;
+        }
+        if (!lab_upload(&l->d_w4_cls, cls)) { rt1w_lab_destroy(l); return RT1W_ERR_DEVICE; }
+        l->n_nodes = (uint32_t)cls.size();
+        l->sphere_media = s->has_media && s->media_bare_spheres;
+        l->w4_ok = l->n_nodes <= (uint32_t)LAB_W4_NODE_CAP && s->stack_need + 2u <= (uint32_t)LAB_W4_STACK && (!s->has_media || l->sphere_media);
+        l->stack_need = s->stack_need;
+    }
     *out = l;
     return RT1W_OK;
 }
@@ -890,6 +1081,7 @@ void rt1w_lab_destroy(rt1w_lab* l) {
     if (l->d_inner32) (void)hipFree(l->d_inner32);
     if (l->d_w3_nodes) (void)hipFree(l->d_w3_nodes);
     if (l->d_w3_pairs) (void)hipFree(l->d_w3_pairs);
+    if (l->d_w4_cls) (void)hipFree(l->d_w4_cls);
     if (l->d_w2_inner) (void)hipFree(l->d_w2_inner);
     if (l->d_w2_wref) (void)hipFree(l->d_w2_wref);
     if (l->ev0) (void)hipEventDestroy(l->ev0);
@@ -994,14 +1186,20 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
     if (mode == 6 && !l->w2_ok) { rt1w::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 10) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if ((mode == 11 || mode == 13) && !l->w4_ok) { rt1w::set_error("W4: more than 8192 nodes, a deeper stack than the experiment's, or a medium whose boundary is not a bare sphere"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 12 && !l->sphere_media) { rt1w::set_error("W0c of the sphere-media kernels: not such a scene"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode < 0 || mode > 13) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;
     const uint32_t box_steps = params && params[3] ? params[3] : 1u;
     int per_cu = 0;
     const void* fn = nullptr;
-    if (mode == 10) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4, true> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4, true> : (const void*)lab_trace_w0<RtCfgV2, 4, true>);
+    typedef RtCfgSphereMedia<RtCfgV3> LabCfgSM;
+    if (mode == 11) fn = l->variant == 5 ? (const void*)lab_trace_w4<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w4<LabCfgSM, 4> : (const void*)lab_trace_w4<RtCfgV2, 4>);
+    else if (mode == 13) fn = l->variant == 5 ? (const void*)lab_trace_w4<RtCfgV5, 0> : (l->variant == 3 ? (const void*)lab_trace_w4<LabCfgSM, 0> : (const void*)lab_trace_w4<RtCfgV2, 0>);
+    else if (mode == 12) fn = (const void*)lab_trace_w0<LabCfgSM, 4, true>;
+    else if (mode == 10) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4, true> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4, true> : (const void*)lab_trace_w0<RtCfgV2, 4, true>);
     else if (mode == 8) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 4> : (const void*)lab_trace_w3<RtCfgV2, 4>);
     else if (mode == 9) fn = l->variant == 5 ? (const void*)lab_trace_w3<RtCfgV5, 0> : (l->variant == 3 ? (const void*)lab_trace_w3<RtCfgV3, 0> : (const void*)lab_trace_w3<RtCfgV2, 0>);
     else if (mode == 7) fn = l->variant == 5 ? (const void*)lab_trace_w0<RtCfgV5, 4> : (l->variant == 3 ? (const void*)lab_trace_w0<RtCfgV3, 4> : (const void*)lab_trace_w0<RtCfgV2, 4>);
@@ -1019,7 +1217,15 @@ int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats,
     for (int rep = 0; rep < (repeats > 0 ? repeats : 1); ++rep) {
         (void)hipMemsetAsync(l->d_counter, 0, 16 * sizeof(unsigned long long), l->stream);
         (void)hipEventRecord(l->ev0, l->stream);
-        if (mode == 10) {
+        if (mode == 11 || mode == 13) {
+            const uint32_t idle = params && params[0] ? params[0] : 160u;
+#define LAB_W4(CFG, BS) hipLaunchKernelGGL((lab_trace_w4<CFG, BS>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_w4_cls, l->d_rays, l->n_rays, l->d_hits, l->d_counter, idle, l->d_counter + 1)
+            if (mode == 11) { if (l->variant == 5) LAB_W4(RtCfgV5, 4); else if (l->variant == 3) LAB_W4(LabCfgSM, 4); else LAB_W4(RtCfgV2, 4); }
+            else { if (l->variant == 5) LAB_W4(RtCfgV5, 0); else if (l->variant == 3) LAB_W4(LabCfgSM, 0); else LAB_W4(RtCfgV2, 0); }
+#undef LAB_W4
+        } else if (mode == 12) {
+            hipLaunchKernelGGL((lab_trace_w0<LabCfgSM, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
+        } else if (mode == 10) {
             if (l->variant == 5) hipLaunchKernelGGL((lab_trace_w0<RtCfgV5, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else if (l->variant == 3) hipLaunchKernelGGL((lab_trace_w0<RtCfgV3, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);
             else hipLaunchKernelGGL((lab_trace_w0<RtCfgV2, 4, true>), dim3(grid), dim3(RT_BLOCK), 0, l->stream, l->view, l->d_rays, l->n_rays, l->d_hits, l->d_counter, refill, l->d_counter + 1);

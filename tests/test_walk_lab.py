@@ -26,7 +26,7 @@ def test_walk_candidates_answer_like_the_product_walk(rt, gpu_ctx_factory):
              (rt.Scene.reference(7).set_bvh_build(True), 96, 96, 2, 24), (rt.Scene.reference(6), 96, 96, 2, 12),
              (rt.Scene.reference(5), 96, 96, 2, 12)]
     cases += [(random_scene_pair(2000 + s)[0], 48, 32, 2, 10) for s in range(8)]
-    n_w1 = n_w2 = 0
+    n_w1 = n_w2 = n_w4 = 0
     for sc, W, H, spp, bounces in cases:
         ctx = gpu_ctx_factory(sc)
         lab = wl.Lab(ctx)
@@ -41,6 +41,13 @@ def test_walk_candidates_answer_like_the_product_walk(rt, gpu_ctx_factory):
         assert wl.same_hits(base, lab.trace(8, repeats=1))           # pair records for the steering BVH nodes (+ box-only steps)
         assert wl.same_hits(base, lab.trace(9, repeats=1))
         assert wl.same_hits(base, lab.trace(10, repeats=1))          # box-only steps with the top of the stack in a register
+        for mode, idle in ((11, 160), (11, 32), (13, 96), (12, 32)):  # W4: walks regrouped across the waves of a workgroup by the kind of
+            try:                                                     # their next entry (12: W0c as the sphere-media kernels run it)
+                w4 = lab.trace(mode, repeats=1, refill=idle)
+                assert wl.same_hits(base, w4), (mode, idle, sc.info())
+                n_w4 += mode != 12
+            except rt.Rt1wError as e:
+                assert e.code == rt.ERR_UNSUPPORTED
         try:
             w2 = lab.trace(6, repeats=1, votes=24)                   # the phased walk, every scene
             assert wl.same_hits(base, w2), sc.info()
@@ -55,4 +62,4 @@ def test_walk_candidates_answer_like_the_product_walk(rt, gpu_ctx_factory):
             n_w1 += 1
         lab.close()
         ctx.close()
-    assert n_w1 >= 1 and n_w2 >= 10
+    assert n_w1 >= 1 and n_w2 >= 10 and n_w4 >= 12
