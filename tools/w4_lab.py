@@ -36,6 +36,14 @@ def main():
             r = lab.trace(mode, refill=rf, repeats=2, want_hits=False)
             print(f"mode {mode}: {n / r['ms'] / 1e3:8.1f} Mrays/s", flush=True)
         return
+    if "--occ" in sys.argv:  # how much the walk by itself gains from more resident waves (workgroups per CU)
+        for mode, label in ((0, "W0"), (12 if lab.variant == 3 else 10, "W0c")):
+            for bpc in (1, 2, 3, 4, 5):
+                r = lab.trace(mode, refill=40, blocks_per_cu=bpc, want_hits=False)
+                print(f"{label:4s} {r['stats'][7]} workgroups/CU: {n / r['ms'] / 1e3:8.1f} Mrays/s", flush=True)
+                if r["stats"][7] < bpc:
+                    break
+        return
     base = lab.trace(0, refill=32)
     print(f"W0   {n / base['ms'] / 1e3:8.1f} Mrays/s", flush=True)
     modes = [(10, "W0c")]
