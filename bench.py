@@ -268,6 +268,8 @@ def kernel_name(st):
         return "rt_jit_sorted"
     if flags & 128:
         return "rt_render_kernel_pw<V%d>" % st["variant"]
+    if flags & 512:
+        return "rt_render_kernel_ss<V%d, sphere media>" % st["variant"]
     if flags & 256:
         return "rt_render_kernel<V%d, sphere media>" % st["variant"]
     return ("rt_render_kernel_sorted<V%d>" if (flags & 1) else "rt_render_kernel<V%d>") % st["variant"]

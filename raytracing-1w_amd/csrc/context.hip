@@ -63,6 +63,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_pw(
     rt_render_plain_body<Cfg, false, true>(sc, f, partial, counters, &pw);
 }
 
+/* sliced stack walk + reordering of the finished paths at the end of every slice (rt_kernel_plain.h: rt_render_ss_body) */
+template <class Cfg, int CAP, int PARTS>
+__global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+                                                                           unsigned long long* __restrict__ counters) {
+    rt_render_ss_body<Cfg, CAP, PARTS>(sc, f, partial, counters);
+}
+
 /* the reordering kernel proper (rt_kernel_sorted.h) */
 template <class Cfg>
 __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
@@ -159,6 +166,7 @@ struct rt1w_context {
     double* d_out = nullptr; size_t out_bytes = 0;
     int grid[RT_N_VARIANTS] = {};
     int grid_sphere_media[RT_N_VARIANTS] = {};
+    int grid_ss[RT_N_VARIANTS] = {};
     bool sphere_media = false; /* every medium of the scene is bounded by a bare Sphere: g_kernels_sphere_media serve */
     int grid_sorted[RT_N_VARIANTS] = {};
     int grid_cached[RT_N_VARIANTS] = {};
@@ -207,6 +215,9 @@ static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV
 /* the stack variants with media, for scenes whose media are all bounded by a bare Sphere (rt_flat.h: RtCfgSphereMedia) */
 static render_kernel_t const g_kernels_sphere_media[RT_N_VARIANTS] = {nullptr, nullptr, nullptr, rt_render_kernel<RtCfgSphereMedia<RtCfgV3>>,
                                                                       rt_render_kernel<RtCfgSphereMedia<RtCfgV4>>, nullptr};
+/* the same scenes with the finished paths reordered across the workgroup at the end of every slice (rt_render_ss_body): the default for them */
+static render_kernel_t const g_kernels_ss[RT_N_VARIANTS] = {nullptr, nullptr, nullptr, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV3>, RT_STACK_CAP, 3>,
+                                                            rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV4>, RT_STACK_CAP, 3>, nullptr};
 /* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
  * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
 static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr, rt_render_kernel<RtCfgV5, true>};
@@ -317,7 +328,7 @@ void lane_destroy(RtLane& l) {
     l = RtLane();
 }
 
-struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false, sphere_media = false; };
+struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false, sphere_media = false, ss = false; };
 int specialise_f32(rt1w_context* c, bool allow_compile);
 
 /* what the launch will need, without launching: frame, variant, launch shape */
@@ -392,7 +403,8 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     L.sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
     L.sphere_media = !L.sorted && !L.cached && c->sphere_media && g_kernels_sphere_media[variant] != nullptr && !(p->flags & RT1W_CLASSIC_WALK) && !getenv("RT1W_CLASSIC_WALK");
-    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant]));
+    L.ss = L.sphere_media && g_kernels_ss[variant] != nullptr && !(p->flags & RT1W_UNSORTED) && !getenv("RT1W_NO_SLICE_SORT");
+    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.ss ? c->grid_ss[variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant])));
     L.block = L.sorted ? RT_SORT_BLOCK : RT_BLOCK;
     return RT1W_OK;
 }
@@ -439,7 +451,7 @@ int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const
     } else if (L.pw) {
         hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
     } else {
-        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant])),
+        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.ss ? g_kernels_ss[L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant]))),
                            dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
     }
     {
@@ -465,7 +477,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u) | (L.sphere_media ? 256u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u) | (L.sphere_media ? 256u : 0u) | (L.ss ? 512u : 0u);
     }
     return RT1W_OK;
 }
@@ -759,6 +771,14 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
             }
             if (per_cu < 1) per_cu = 1;
             c->grid_sphere_media[v] = prop.multiProcessorCount * per_cu;
+        }
+        if (g_kernels_ss[v]) {
+            per_cu = 0;
+            if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_ss[v], RT_BLOCK, 0), "occupancy query")) {
+                rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+            }
+            if (per_cu < 1) per_cu = 1;
+            c->grid_ss[v] = prop.multiProcessorCount * per_cu;
         }
         if (g_kernels_cached[v]) {
             per_cu = 0;

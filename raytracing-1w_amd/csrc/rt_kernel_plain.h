@@ -359,4 +359,260 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
 }
 
 
+/* ---- sliced stack walk + workgroup-level reordering of the paths whose walk has ended ("ss") ---------------------------------
+ * PMC of the final_scene kernel: 18 600 VALU instructions per wave and 64 segments, of which the walk by itself needs 8 500
+ * (the lab's W0c): more than half are shading, hit records and regeneration, run by each wave for the ~40 lanes that left the
+ * slice -- every material's, every texture's and every primitive kind's code for two or three lanes each (a Perlin-textured
+ * sphere: 7 octaves of noise for one lane).  The reordering kernel of the small scenes (rt_kernel_sorted.h) cures exactly that,
+ * but it traces every walk to its end between two barriers.  Here the two are combined: every wave walks its slice on its own
+ * (no barrier inside the walk), and at the END of a slice the workgroup sorts the paths whose walk is over by what they do next
+ * (Lambertian with a solid colour / Lambertian with a texture / dielectric / metal / isotropic / terminal / retired) and hands
+ * each to a lane that is free -- the lanes still walking keep their paths, their walk state and their stack columns.  The sorted
+ * rank r of a finished path and the index q of a free lane both run from 0 to the number of finished paths: a finished lane
+ * writes its state to slot r of the exchange buffer, a free lane reads slot q.  A path is a pure function of its state, so the
+ * frame is bit-identical to the plain kernel's (the GPU suite compares with the CPU build of the core). */
+/* CAP = stack entries per lane, PARTS = rounds of the exchange.  Built as (32, 3): 32 KB of stacks + 9 qwords x 256 paths = 18 KB, three
+ * workgroups per CU, six barriers per slice; (16, 2) -- 16 KB + 27 KB, four barriers, for walks of at most 16 entries -- measured the
+ * same (306 against 306 Mpaths/s): only the first barrier of a slice waits for anything. */
+#ifndef RT_SS_IDLE
+#define RT_SS_IDLE 40 /* finished walks per wave (RT_SS_WG_SLICE: per workgroup, x 4) that end a slice; final_scene 800x800x100, kernel Mpaths/s:
+                         32: 302, 36: 304, 40: 306-309, 44: 304, 48: 302, 56: 282 (the plain kernel: 273) */
+#endif
+#ifndef RT_SS_WG_SLICE
+#define RT_SS_WG_SLICE 1 /* the slice ends for the whole workgroup at once: every wave publishes how many of its walks have ended and all stop
+                            when the workgroup's total reaches 4 x RT_SS_IDLE -- the waves then reach the sort's barrier within a round of each other.
+                            Measured: with every wave ending its own slice (0) the reordering only ties the plain kernel (272 against 273 Mpaths/s:
+                            31 % fewer VALU instructions, but 69 % of the wave cycles waiting instead of 50 %); with this, 306-309 */
+#endif
+#define RT_SS_KEYS 7u /* Lambertian with a solid colour, Lambertian with a texture, dielectric, metal, isotropic, terminal, retired (splitting the first by
+                         the kind of primitive hit, rect or not: measured, no difference) */
+template <class Cfg, int CAP, int PARTS>
+__device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
+                                                  unsigned long long* __restrict__ counters) {
+    static_assert(!Cfg::sweep && RT_WALK_MODE == 0, "stack-walk variants only");
+    constexpr int RT_SS_PER = (RT_XCH_QW + PARTS - 1) / PARTS;
+    __shared__ uint32_t stack_mem[CAP * RT_BLOCK];
+    __shared__ unsigned long long xch[RT_SS_PER * RT_BLOCK];
+    __shared__ uint32_t cnt[4][RT_SS_KEYS + 1u]; /* [wave][key]; last column: lanes of the wave that are not walking */
+    __shared__ uint32_t ss_done[2][4];           /* [slice parity][wave]: walks of the wave that have ended in this slice */
+    uint32_t parity = 0u;
+    if (threadIdx.x < 8u) ss_done[threadIdx.x >> 2][threadIdx.x & 3u] = 0u;
+    __syncthreads();
+    LdsStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.sp = 0;
+    RtGlobalNodes ns;
+    ns.p = sc.nodes;
+    const unsigned long long n_items = rt_item_count(f);
+    const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long item = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+    bool fresh = true, have = false, retired = false;
+    uint32_t px = 0, py = 0, chunk = 0, s = 0;
+    RtV3d sum = rt_v3d(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+    RtPath path;
+    path.alive = false;
+    path.depth_left = 0u;
+    path.ray.o = path.ray.d = path.beta = path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+    path.ray.time = RT_R(0.0);
+    path.rng = rt_rng_make(0u, 0u, 0u, f.global_seed, RT_DOMAIN_RENDER);
+    unsigned long long segs = 0;
+    bool walking = false;
+    double w_best_t = RT_INF;
+    uint32_t w_best_prim = RT_NONE, w_best_scope = RT_NONE, w_scope = RT_NONE;
+    for (;;) {
+        /* 1. regeneration: next sample of the lane's item, or a new item (lanes between two walks only) */
+        if (!walking && !path.alive && !retired) {
+            const uint32_t s_end = chunk * f.chunk + f.chunk < f.spp ? chunk * f.chunk + f.chunk : f.spp;
+            if (have && s == s_end) {
+                rt_f64* dst = partial + ((unsigned long long)chunk * npix + (unsigned long long)py * f.tile_w + px) * 3ull;
+                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
+                have = false;
+            }
+            while (!have) {
+                if (!fresh) {
+                    const unsigned long long need = __ballot(1);
+                    const uint32_t cntn = (uint32_t)__popcll(need);
+                    const uint32_t rank = lane_prefix(need);
+                    unsigned long long base_item = 0;
+                    if (rank == 0u) base_item = atomicAdd(&counters[0], (unsigned long long)cntn);
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_item);
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_item >> 32));
+                    item = (((unsigned long long)hi << 32) | lo) + rank;
+                }
+                fresh = false;
+                if (item >= n_items) break;
+                rt_item_decode(f, item, px, py, chunk);
+                if (px < f.tile_w && py < f.tile_h) {
+                    s = chunk * f.chunk;
+                    sum = rt_v3d(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+                    have = true;
+                }
+            }
+            if (!have) retired = true;
+            else rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
+        }
+        /* 2. a path between two walks starts its next segment's walk */
+        if (!walking && !retired) {
+            segs += path.depth_left != 0u ? 1ull : 0ull;
+            w_best_t = RT_INF; w_best_prim = RT_NONE; w_best_scope = RT_NONE; w_scope = RT_NONE;
+            if (path.depth_left != 0u) {
+                stk.push(sc.root); walking = true;
+#if RT_MEDIA_PREFILL
+                if (Cfg::media) rt_rng_fill(path.rng);
+#endif
+            }
+        }
+        /* 3. one slice of the wave's walks (the plain kernel's loop) */
+        RtTrace tr;
+        tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = retired ? RT_CLS_IDLE : RT_CLS_TERMINAL;
+        uint32_t key = retired ? 6u : 5u;
+        if (walking) {
+            RtWalk k;
+            k.w.o = path.ray.o; k.w.d = path.ray.d;
+            k.inv_w = rt_inv3(k.w.d);
+            k.time = path.ray.time; k.t_min = RT_R(0.001); k.tmin_nan = false; k.base = 0;
+            k.best_t = w_best_t; k.best_prim = w_best_prim; k.best_scope = w_best_scope; k.scope = w_scope;
+            if (Cfg::scope_depth == 0 || w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
+            else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }
+            const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
+            const uint32_t stop_at = lanes_here > (uint32_t)RT_SS_IDLE ? lanes_here - (uint32_t)RT_SS_IDLE : 0u;
+            const uint32_t lead_ = (uint32_t)__ffsll((long long)__ballot(1)) - 1u; /* the first walking lane publishes for the wave */
+            (void)stop_at; (void)lead_;
+            /* wave-uniform: does the slice go on?  (n = lanes of this wave still walking; a macro, see RT_SLICE_BOX_STEPS_HERE) */
+#define RT_SS_GOES_ON(n, out)                                                                                         \
+    if constexpr (RT_SS_WG_SLICE) {                                                                                   \
+        if (lane == lead_) ss_done[parity][wave] = lanes_here - (n);                                                  \
+        const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];    \
+        out = (n) != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE;                                                        \
+    } else out = (n) > stop_at;
+#define RT_SS_BOX_STEPS_HERE()                                                                                      \
+    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) { \
+        rt_walk_box_run<Cfg, RT_SLICE_BOX_STEPS(Cfg)>(ns, k, stk);                                                  \
+    } else if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {                                                             \
+        bool between_boxes = true;                                                                                  \
+        for (int extra = 0; extra < RT_SLICE_BOX_STEPS(Cfg); ++extra)                                               \
+            if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);          \
+    }
+            for (;;) {
+                const bool more = !rt_walk_done(k, stk);
+                bool on_; { const uint32_t n_ = (uint32_t)__popcll(__ballot(more)); RT_SS_GOES_ON(n_, on_) }
+                if (!on_) break;
+                if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
+                if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
+                RT_SS_BOX_STEPS_HERE()
+                if constexpr (Cfg::media && RT_SLICE_HEAVY_EVERY > 1) {
+                    const bool more2 = !rt_walk_done(k, stk);
+                    { const uint32_t n_ = (uint32_t)__popcll(__ballot(more2)); RT_SS_GOES_ON(n_, on_) }
+                    if (!on_) break;
+                    if (more2) rt_walk_light_step<Cfg>(sc, ns, k, stk);
+                    RT_SS_BOX_STEPS_HERE()
+                }
+            }
+#undef RT_SS_BOX_STEPS_HERE
+#undef RT_SS_GOES_ON
+            if (rt_walk_done(k, stk)) {
+                walking = false;
+                tr.t = k.best_t; tr.prim = k.best_prim; tr.scope = k.best_scope;
+                if (tr.prim != RT_NONE) {
+                    const uint32_t kf = RT_MAT_KINDF(ns.hot(tr.prim).mat), mk = kf & 0xFFu;
+                    tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
+                           : mk == RT_MAT_METAL ? RT_CLS_METAL : mk == RT_MAT_ISOTROPIC ? RT_CLS_OTHER : RT_CLS_TERMINAL;
+                    key = mk == RT_MAT_LAMBERTIAN ? ((kf & RT_MAT_SOLID) ? 0u : 1u) : mk == RT_MAT_DIELECTRIC ? 2u
+                        : mk == RT_MAT_METAL ? 3u : mk == RT_MAT_ISOTROPIC ? 4u : 5u;
+                }
+            } else {
+                w_best_t = k.best_t; w_best_prim = k.best_prim; w_best_scope = k.best_scope; w_scope = k.scope;
+            }
+        }
+        /* 4. rank of every finished path in (key, wave, lane) order; index of every free lane in (wave, lane) order */
+        const bool fin = !walking;
+        uint32_t my_rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < RT_SS_KEYS; ++c) {
+            const unsigned long long m = __ballot(fin && key == c);
+            if (fin && key == c) my_rank = lane_prefix(m);
+            if (lane == 0u) cnt[wave][c] = (uint32_t)__popcll(m);
+        }
+        const unsigned long long free_m = __ballot(fin);
+        uint32_t q = lane_prefix(free_m);
+        if (lane == 0u) cnt[wave][RT_SS_KEYS] = (uint32_t)__popcll(free_m);
+        __syncthreads();
+        if constexpr (RT_SS_WG_SLICE) { if (lane == 0u) ss_done[parity ^ 1u][wave] = 0u; parity ^= 1u; } /* the next slice's counters: nobody reads them before the barriers below */
+        uint32_t dest = my_rank, idle_total = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < RT_SS_KEYS; ++c) {
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                const uint32_t v = cnt[w][c];
+                if (c < key || (c == key && w < wave)) dest += v;
+                if (c == RT_SS_KEYS - 1u) idle_total += v;
+            }
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) { const uint32_t v = cnt[w][RT_SS_KEYS]; if (w < wave) q += v; }
+        if (idle_total == (uint32_t)RT_BLOCK) break; /* every lane of the workgroup has retired (uniform; none can be walking) */
+        /* 5. the finished paths change lanes */
+        {
+            unsigned long long st[RT_XCH_QW];
+#define RT_PK2(a, b) (((unsigned long long)(b) << 32) | (unsigned long long)(uint32_t)(a))
+            st[0] = rt_d2u(path.ray.o.x); st[1] = rt_d2u(path.ray.o.y); st[2] = rt_d2u(path.ray.o.z);
+            st[3] = rt_d2u(path.ray.d.x); st[4] = rt_d2u(path.ray.d.y); st[5] = rt_d2u(path.ray.d.z);
+            st[6] = rt_d2u(path.ray.time);
+            st[7] = rt_d2u(path.beta.x); st[8] = rt_d2u(path.beta.y); st[9] = rt_d2u(path.beta.z);
+            st[10] = rt_d2u(sum.x); st[11] = rt_d2u(sum.y); st[12] = rt_d2u(sum.z);
+            st[13] = rt_d2u(tr.t);
+            st[14] = RT_PK2(path.rng.k0, path.rng.k1); st[15] = RT_PK2(path.rng.c1, path.rng.blk);
+            st[16] = RT_PK2(path.rng.left, path.rng.bv); st[17] = RT_PK2(path.rng.a0, path.rng.a1);
+            st[18] = RT_PK2(path.rng.a2, path.rng.a3); st[19] = RT_PK2(path.rng.b0, path.rng.b1);
+            st[20] = RT_PK2(path.rng.b2, path.rng.b3);
+            st[21] = RT_PK2(tr.prim, tr.scope); st[22] = RT_PK2(tr.cls, path.depth_left);
+            st[23] = RT_PK2(px, py); st[24] = RT_PK2(chunk, s);
+            st[25] = RT_PK2((have ? 1u : 0u) | (retired ? 2u : 0u) | (path.alive ? 4u : 0u), 0u);
+#undef RT_PK2
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+                if (part) __syncthreads(); /* the previous round's readers are done with the buffer */
+                if (fin) {
+#pragma unroll
+                    for (int i = part * RT_SS_PER; i < (part + 1) * RT_SS_PER && i < RT_XCH_QW; ++i) xch[(i - part * RT_SS_PER) * RT_BLOCK + dest] = st[i];
+                }
+                __syncthreads();
+                if (fin) {
+#pragma unroll
+                    for (int i = part * RT_SS_PER; i < (part + 1) * RT_SS_PER && i < RT_XCH_QW; ++i) st[i] = xch[(i - part * RT_SS_PER) * RT_BLOCK + q];
+                }
+            }
+            if (fin) {
+#define RT_UP2(v, a, b) do { (a) = (uint32_t)(v); (b) = (uint32_t)((v) >> 32); } while (0)
+                path.ray.o.x = rt_u2d(st[0]); path.ray.o.y = rt_u2d(st[1]); path.ray.o.z = rt_u2d(st[2]);
+                path.ray.d.x = rt_u2d(st[3]); path.ray.d.y = rt_u2d(st[4]); path.ray.d.z = rt_u2d(st[5]);
+                path.ray.time = rt_u2d(st[6]);
+                path.beta.x = rt_u2d(st[7]); path.beta.y = rt_u2d(st[8]); path.beta.z = rt_u2d(st[9]);
+                sum.x = rt_u2d(st[10]); sum.y = rt_u2d(st[11]); sum.z = rt_u2d(st[12]);
+                tr.t = rt_u2d(st[13]);
+                RT_UP2(st[14], path.rng.k0, path.rng.k1); RT_UP2(st[15], path.rng.c1, path.rng.blk);
+                RT_UP2(st[16], path.rng.left, path.rng.bv); RT_UP2(st[17], path.rng.a0, path.rng.a1);
+                RT_UP2(st[18], path.rng.a2, path.rng.a3); RT_UP2(st[19], path.rng.b0, path.rng.b1);
+                RT_UP2(st[20], path.rng.b2, path.rng.b3);
+                RT_UP2(st[21], tr.prim, tr.scope); RT_UP2(st[22], tr.cls, path.depth_left);
+                RT_UP2(st[23], px, py); RT_UP2(st[24], chunk, s);
+                const uint32_t flags = (uint32_t)st[25];
+                have = (flags & 1u) != 0u; retired = (flags & 2u) != 0u; path.alive = (flags & 4u) != 0u;
+#undef RT_UP2
+            }
+        }
+        /* 6. shading, coherent within a wave after the sort */
+        if (fin && !retired) {
+            rt_path_shade<Cfg>(sc, path, tr);
+            if (!path.alive) {
+                sum = rt_v3d_add(sum, path.radiance);
+                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+                ++s;
+            }
+        }
+    }
+    if (segs) atomicAdd(&counters[1], segs);
+}
+
 #endif

@@ -753,6 +753,32 @@ def test_sphere_media_kernels_are_bit_identical(rt, gpu_ctx_factory):
     ctx.close()
 
 
+def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
+    """The default kernels of sphere-media scenes (final_scene) reorder the paths whose walk has ended across the workgroup at the
+    end of every slice of the stack walk (rt_kernel_plain.h: rt_render_ss_body; stats.sorted bit 9 = 512): which lane shades a
+    path changes, nothing else.  Same frame and segment count as the plain sliced kernel (RT1W_UNSORTED) and as the CPU build of
+    the core -- reference tree, SAH tree, near-far order (V4), tiles, sample offsets, frames smaller than one workgroup's lanes
+    (retired lanes take part in the exchange) and several samples per work item."""
+    for sah, near_far in ((False, False), (True, True)):
+        sc = rt.Scene.reference(7, build_seed=1)
+        if sah:
+            sc.set_bvh_build(True)
+        if near_far:
+            sc.set_walk_order(True)
+        ctx = gpu_ctx_factory(sc)
+        for W, H, spp, kw in ((64, 64, 6, {}), (320, 320, 3, {}), (13, 9, 5, {}), (96, 80, 8, dict(tile=(16, 8, 50, 37), sample_offset=3)),
+                              (48, 48, 24, dict(chunk=8))):
+            a, sa = ctx.render(W, H, spp, **kw)
+            b, sb = ctx.render(W, H, spp, unsorted=True, **kw)
+            assert sa["sorted"] & 512 and sa["sorted"] & 256 and not (sb["sorted"] & 512) and sb["sorted"] & 256, (sa["sorted"], sb["sorted"])
+            assert sa["variant"] == sb["variant"] == (4 if near_far else 3)
+            assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, near_far, W, H, spp, kw)
+        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=rt.default_chunk(64, 64, 6))
+        a, sa = ctx.render(64, 64, 6)
+        assert sa["sorted"] & 512 and sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), (sah, near_far)
+        ctx.close()
+
+
 def test_precompiled_kernels_load_on_a_host_without_the_runtime_compiler(rt):
     """A host that cannot compile (no libhiprtc: RT1W_NO_HIPRTC hides it) still runs the scene-specialised kernels the build
     precompiled under <package>/kernels -- their key no longer contains the host's compiler id (round-2 advice)."""
