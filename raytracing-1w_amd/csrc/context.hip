@@ -70,6 +70,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss(
     rt_render_ss_body<Cfg, CAP, PARTS>(sc, f, partial, counters);
 }
 
+/* the same for sphere scenes: the pair walk in slices + the reordering of the finished paths (RT_PW_SS_STACK entries per lane instead of
+ * RT_PW_STACK: what leaves room for the exchange buffer next to the pair walk's stacks and queues at three workgroups per CU) */
+#define RT_PW_SS_STACK 12
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_pw_ss(RtSceneView sc, RtPwView pw, RtFrame f, double* __restrict__ partial,
+                                                                              unsigned long long* __restrict__ counters) {
+    rt_render_ss_body<Cfg, RT_PW_SS_STACK, 3, true>(sc, f, partial, counters, &pw);
+}
+
 /* the reordering kernel proper (rt_kernel_sorted.h) */
 template <class Cfg>
 __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
@@ -166,7 +175,7 @@ struct rt1w_context {
     double* d_out = nullptr; size_t out_bytes = 0;
     int grid[RT_N_VARIANTS] = {};
     int grid_sphere_media[RT_N_VARIANTS] = {};
-    int grid_ss[RT_N_VARIANTS] = {};
+    int grid_ss[2][RT_N_VARIANTS] = {};
     bool sphere_media = false; /* every medium of the scene is bounded by a bare Sphere: g_kernels_sphere_media serve */
     int grid_sorted[RT_N_VARIANTS] = {};
     int grid_cached[RT_N_VARIANTS] = {};
@@ -188,7 +197,7 @@ struct rt1w_context {
     void* d_pw_inner = nullptr; void* d_pw_groups = nullptr;
     RtPwView pw{};
     bool pw_ok = false; std::string pw_why;
-    int pw_grid = 0;
+    int pw_grid = 0, pw_ss_grid = 0;
     /* host copies of the flat arrays the two opt-in modes convert on first use (a scene may be destroyed before its contexts) */
     std::vector<RtNode> h_nodes, h_lights; std::vector<RtMaterial> h_materials; std::vector<RtTexture> h_textures; std::vector<RtPerlin> h_perlin;
     int f32_grid[RT_N_VARIANTS][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -215,9 +224,11 @@ static render_kernel_t const g_kernels[RT_N_VARIANTS] = {rt_render_kernel<RtCfgV
 /* the stack variants with media, for scenes whose media are all bounded by a bare Sphere (rt_flat.h: RtCfgSphereMedia) */
 static render_kernel_t const g_kernels_sphere_media[RT_N_VARIANTS] = {nullptr, nullptr, nullptr, rt_render_kernel<RtCfgSphereMedia<RtCfgV3>>,
                                                                       rt_render_kernel<RtCfgSphereMedia<RtCfgV4>>, nullptr};
-/* the same scenes with the finished paths reordered across the workgroup at the end of every slice (rt_render_ss_body): the default for them */
-static render_kernel_t const g_kernels_ss[RT_N_VARIANTS] = {nullptr, nullptr, nullptr, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV3>, RT_STACK_CAP, 3>,
-                                                            rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV4>, RT_STACK_CAP, 3>, nullptr};
+/* the stack-walk kernels with the finished paths reordered across the workgroup at the end of every slice (rt_render_ss_body): the default
+ * for the scenes they cover; [1] = the sphere-media builds */
+static render_kernel_t const g_kernels_ss[2][RT_N_VARIANTS] = {
+    {nullptr, nullptr, rt_render_kernel_ss<RtCfgV2, RT_STACK_CAP, 3>, rt_render_kernel_ss<RtCfgV3, RT_STACK_CAP, 3>, nullptr, rt_render_kernel_ss<RtCfgV5, RT_STACK_CAP, 3>},
+    {nullptr, nullptr, nullptr, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV3>, RT_STACK_CAP, 3>, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV4>, RT_STACK_CAP, 3>, nullptr}};
 /* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
  * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
 static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr, rt_render_kernel<RtCfgV5, true>};
@@ -398,13 +409,15 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     /* sphere scenes: the pair walk (same frames, bit for bit), unless the caller asks for the one-entry-per-step walk */
     if (c->pw_ok && variant == 5 && !(p->flags & (RT1W_CLASSIC_WALK | RT1W_LDS_NODES | RT1W_WAVEFRONT)) && !getenv("RT1W_CLASSIC_WALK")) {
         L.pw = true; L.sorted = false; L.cached = false; L.grid = c->pw_grid; L.block = RT_BLOCK;
+        L.ss = c->pw_ss_grid > 0 && !(p->flags & RT1W_UNSORTED) && !getenv("RT1W_NO_SLICE_SORT");
+        if (L.ss) L.grid = c->pw_ss_grid;
         return RT1W_OK;
     }
     L.sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
     L.sphere_media = !L.sorted && !L.cached && c->sphere_media && g_kernels_sphere_media[variant] != nullptr && !(p->flags & RT1W_CLASSIC_WALK) && !getenv("RT1W_CLASSIC_WALK");
-    L.ss = L.sphere_media && g_kernels_ss[variant] != nullptr && !(p->flags & RT1W_UNSORTED) && !getenv("RT1W_NO_SLICE_SORT");
-    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.ss ? c->grid_ss[variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant])));
+    L.ss = !L.sorted && !L.cached && g_kernels_ss[L.sphere_media ? 1 : 0][variant] != nullptr && !(p->flags & RT1W_UNSORTED) && !getenv("RT1W_NO_SLICE_SORT");
+    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.ss ? c->grid_ss[L.sphere_media ? 1 : 0][variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant])));
     L.block = L.sorted ? RT_SORT_BLOCK : RT_BLOCK;
     return RT1W_OK;
 }
@@ -449,9 +462,10 @@ int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const
         void* args[] = {&view, &frame, &partial, &counters};
         if (!hip_ok(hipModuleLaunchKernel(c->jit_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised kernel launch")) return RT1W_ERR_DEVICE;
     } else if (L.pw) {
-        hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
+        if (L.ss) hipLaunchKernelGGL(rt_render_kernel_pw_ss<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
+        else hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
     } else {
-        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.ss ? g_kernels_ss[L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant]))),
+        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.ss ? g_kernels_ss[L.sphere_media ? 1 : 0][L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant]))),
                            dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
     }
     {
@@ -772,13 +786,14 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
             if (per_cu < 1) per_cu = 1;
             c->grid_sphere_media[v] = prop.multiProcessorCount * per_cu;
         }
-        if (g_kernels_ss[v]) {
+        for (int sm = 0; sm < 2; ++sm) {
+            if (!g_kernels_ss[sm][v]) continue;
             per_cu = 0;
-            if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_ss[v], RT_BLOCK, 0), "occupancy query")) {
+            if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_ss[sm][v], RT_BLOCK, 0), "occupancy query")) {
                 rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
             }
             if (per_cu < 1) per_cu = 1;
-            c->grid_ss[v] = prop.multiProcessorCount * per_cu;
+            c->grid_ss[sm][v] = prop.multiProcessorCount * per_cu;
         }
         if (g_kernels_cached[v]) {
             per_cu = 0;
@@ -815,6 +830,13 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
             c->pw.inner = (const RtPwInner*)c->d_pw_inner; c->pw.groups = (const RtPwGroup*)c->d_pw_groups;
             c->pw_grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
             c->pw_ok = true;
+            if (s->stack_need + 1u <= (uint32_t)RT_PW_SS_STACK) { /* shallow enough for the kernel that also reorders the finished paths */
+                per_cu = 0;
+                if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel_pw_ss<RtCfgV5>, RT_BLOCK, 0), "occupancy query")) {
+                    rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+                }
+                c->pw_ss_grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+            }
         }
     } else c->pw_why = "not a wrapper-free, media-free scene of more than 64 nodes, or its tree is deeper than the pair walk's stack";
     /* the opt-in modes' own data (f32 scene arrays, the wavefront form's walk records) are built at their first use:

@@ -375,8 +375,10 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
  * workgroups per CU, six barriers per slice; (16, 2) -- 16 KB + 27 KB, four barriers, for walks of at most 16 entries -- measured the
  * same (306 against 306 Mpaths/s): only the first barrier of a slice waits for anything. */
 #ifndef RT_SS_IDLE
-#define RT_SS_IDLE 40 /* finished walks per wave (RT_SS_WG_SLICE: per workgroup, x 4) that end a slice; final_scene 800x800x100, kernel Mpaths/s:
-                         32: 302, 36: 304, 40: 306-309, 44: 304, 48: 302, 56: 282 (the plain kernel: 273) */
+/* finished walks per wave (RT_SS_WG_SLICE: per workgroup, x 4) that end a slice.  Measured, kernel Mpaths/s: final_scene 800x800x100 32: 302,
+ * 36: 304, 40: 306-309, 44: 304, 48: 302, 56: 282 (the plain kernel: 273); random_scene 1200x800x100 (pair walk) 32: 842, 40: 907, 48: 933,
+ * 56: 925 (the plain kernel: 878) */
+#define RT_SS_IDLE(Cfg) (Cfg::media ? 40 : 48)
 #endif
 #ifndef RT_SS_WG_SLICE
 #define RT_SS_WG_SLICE 1 /* the slice ends for the whole workgroup at once: every wave publishes how many of its walks have ended and all stop
@@ -386,12 +388,23 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
 #endif
 #define RT_SS_KEYS 7u /* Lambertian with a solid colour, Lambertian with a texture, dielectric, metal, isotropic, terminal, retired (splitting the first by
                          the kind of primitive hit, rect or not: measured, no difference) */
-template <class Cfg, int CAP, int PARTS>
+/* PW: the walk is the pair walk of sphere scenes (rt_walk_pair.h; CAP = its stack entries per lane), else the one-entry-per-step walk */
+template <class Cfg, int CAP, int PARTS, bool PW = false>
 __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
-                                                  unsigned long long* __restrict__ counters) {
+                                                  unsigned long long* __restrict__ counters, const RtPwView* pwp = nullptr) {
     static_assert(!Cfg::sweep && RT_WALK_MODE == 0, "stack-walk variants only");
     constexpr int RT_SS_PER = (RT_XCH_QW + PARTS - 1) / PARTS;
-    __shared__ uint32_t stack_mem[CAP * RT_BLOCK];
+    __shared__ uint32_t stack_mem[PW ? 1 : CAP * RT_BLOCK];
+#if defined(RT_HAVE_PW)
+    __shared__ uint32_t pw_ref[PW ? CAP * RT_BLOCK : 1];
+    __shared__ float pw_ent[PW ? CAP * RT_BLOCK : 1];
+    __shared__ uint32_t pw_q[PW ? RT_PW_QCAP * RT_BLOCK : 1];
+    RtPwLds<RT_BLOCK> pwm;
+    pwm.ref = pw_ref + threadIdx.x; pwm.ent = pw_ent + threadIdx.x; pwm.q = pw_q + threadIdx.x;
+    RtPwLane pwl; pwl.cur = RT_PW_NONE; pwl.qh = 0u; pwl.qn = 0u; pwl.sp = 0;
+#else
+    static_assert(!PW, "no pair walk in this build");
+#endif
     __shared__ unsigned long long xch[RT_SS_PER * RT_BLOCK];
     __shared__ uint32_t cnt[4][RT_SS_KEYS + 1u]; /* [wave][key]; last column: lanes of the wave that are not walking */
     __shared__ uint32_t ss_done[2][4];           /* [slice parity][wave]: walks of the wave that have ended in this slice */
@@ -452,6 +465,86 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             if (!have) retired = true;
             else rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
         }
+        RtTrace tr;
+        tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = retired ? RT_CLS_IDLE : RT_CLS_TERMINAL;
+        uint32_t key = retired ? 6u : 5u;
+#if defined(RT_HAVE_PW)
+        if constexpr (PW) {
+            /* 2. + 3. the pair walk in slices (the plain kernel's loop, rt_render_plain_body), the slice ended for the whole workgroup */
+            const RtPwView& pw = *pwp;
+            if (!walking && !retired) {
+                segs += path.depth_left != 0u ? 1ull : 0ull;
+                w_best_t = RT_INF; w_best_prim = RT_NONE;
+                if (path.depth_left != 0u) {
+                    const double frac0 = (path.ray.time - pw.ms_time0) / (pw.ms_time1 - pw.ms_time0);
+                    if (rt_isnan(frac0)) { pwl.sp = 0; pwl.qn = 0u; pwl.qh = 0u; pwl.cur = RT_PW_NONE; w_scope = 1u; walking = true; } /* w_scope 1: redo marker */
+                    else { w_scope = RT_NONE; walking = rt_pw_begin(pw, pwl, pwm, path.ray.o, rt_inv3(path.ray.d), RT_R(0.001)); }
+                }
+            }
+            if (walking) {
+                const RtV3 o = path.ray.o, d = path.ray.d, inv = rt_inv3(d);
+                const double frac = (path.ray.time - pw.ms_time0) / (pw.ms_time1 - pw.ms_time0);
+                double best_t = w_best_t;
+                uint32_t best_prim = w_best_prim;
+                bool bad = w_scope != RT_NONE;
+                const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
+                const uint32_t stop_at = lanes_here > (uint32_t)RT_SS_IDLE(Cfg) ? lanes_here - (uint32_t)RT_SS_IDLE(Cfg) : 0u;
+                const uint32_t lead_ = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;
+                (void)stop_at; (void)lead_;
+                for (;;) {
+                    const bool more = !bad && !rt_pw_done(pwl);
+                    bool on_;
+                    {
+                        const uint32_t n_ = (uint32_t)__popcll(__ballot(more));
+                        if constexpr (RT_SS_WG_SLICE) {
+                            if (lane == lead_) ss_done[parity][wave] = lanes_here - n_;
+                            const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];
+                            on_ = n_ != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);
+                        } else on_ = n_ > stop_at;
+                    }
+                    if (!on_) break;
+                    const bool can_box = more && rt_pw_can_box(pwl), can_leaf = more && pwl.qn > 0u;
+                    const uint32_t nb = (uint32_t)__popcll(__ballot(can_box)), nl = (uint32_t)__popcll(__ballot(can_leaf));
+                    if (nl >= RT_PW_VOTES || nb == 0u) {
+                        if (can_leaf) {
+                            rt_pw_group_step(pw, pwl, pwm, o, d, inv, frac, RT_R(0.001), best_t, best_prim);
+#pragma unroll
+                            for (int extra = 1; extra < RT_PW_LEAF_STEPS; ++extra)
+                                if (pwl.qn > 0u) rt_pw_group_step(pw, pwl, pwm, o, d, inv, frac, RT_R(0.001), best_t, best_prim);
+                            if (rt_isnan(best_t)) bad = true;
+                        }
+                    } else if (can_box) {
+                        rt_pw_box_step(pw, pwl, pwm, o, inv, RT_R(0.001), best_t);
+#pragma unroll
+                        for (int extra = 1; extra < RT_PW_BOX_STEPS; ++extra)
+                            if (rt_pw_can_box(pwl)) rt_pw_box_step(pw, pwl, pwm, o, inv, RT_R(0.001), best_t);
+                    }
+                }
+                if (bad) {
+                    /* the closest hit turned NaN: the segment is redone by the one-entry-per-step walk on the same LDS words */
+                    LdsStack cs;
+                    cs.base = pw_ref + threadIdx.x; cs.sp = 0;
+                    uint32_t scope_;
+                    rt_traverse_stack<Cfg, true>(sc, ns, sc.root, path.ray, RT_R(0.001), RT_INF, path.rng, cs, best_t, best_prim, scope_);
+                    pwl.cur = RT_PW_NONE; pwl.sp = 0; pwl.qn = 0u; w_scope = RT_NONE;
+                }
+                if (rt_pw_done(pwl)) {
+                    walking = false;
+                    tr.t = best_t; tr.prim = best_prim; tr.scope = RT_NONE;
+                    if (tr.prim != RT_NONE) {
+                        const uint32_t kf = RT_MAT_KINDF(ns.hot(tr.prim).mat), mk = kf & 0xFFu;
+                        tr.cls = mk == RT_MAT_LAMBERTIAN ? RT_CLS_LAMBERT : mk == RT_MAT_DIELECTRIC ? RT_CLS_DIELECTRIC
+                               : mk == RT_MAT_METAL ? RT_CLS_METAL : mk == RT_MAT_ISOTROPIC ? RT_CLS_OTHER : RT_CLS_TERMINAL;
+                        key = mk == RT_MAT_LAMBERTIAN ? ((kf & RT_MAT_SOLID) ? 0u : 1u) : mk == RT_MAT_DIELECTRIC ? 2u
+                            : mk == RT_MAT_METAL ? 3u : mk == RT_MAT_ISOTROPIC ? 4u : 5u;
+                    }
+                } else {
+                    w_best_t = best_t; w_best_prim = best_prim;
+                }
+            }
+        } else
+#endif
+        {
         /* 2. a path between two walks starts its next segment's walk */
         if (!walking && !retired) {
             segs += path.depth_left != 0u ? 1ull : 0ull;
@@ -464,9 +557,6 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             }
         }
         /* 3. one slice of the wave's walks (the plain kernel's loop) */
-        RtTrace tr;
-        tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = retired ? RT_CLS_IDLE : RT_CLS_TERMINAL;
-        uint32_t key = retired ? 6u : 5u;
         if (walking) {
             RtWalk k;
             k.w.o = path.ray.o; k.w.d = path.ray.d;
@@ -476,7 +566,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             if (Cfg::scope_depth == 0 || w_scope == RT_NONE) { k.cur = k.w; k.inv = k.inv_w; }
             else { k.cur = rt_ray_in_scope(sc.nodes, w_scope, k.w); k.inv = rt_inv3(k.cur.d); }
             const uint32_t lanes_here = (uint32_t)__popcll(__ballot(1));
-            const uint32_t stop_at = lanes_here > (uint32_t)RT_SS_IDLE ? lanes_here - (uint32_t)RT_SS_IDLE : 0u;
+            const uint32_t stop_at = lanes_here > (uint32_t)RT_SS_IDLE(Cfg) ? lanes_here - (uint32_t)RT_SS_IDLE(Cfg) : 0u;
             const uint32_t lead_ = (uint32_t)__ffsll((long long)__ballot(1)) - 1u; /* the first walking lane publishes for the wave */
             (void)stop_at; (void)lead_;
             /* wave-uniform: does the slice go on?  (n = lanes of this wave still walking; a macro, see RT_SLICE_BOX_STEPS_HERE) */
@@ -484,7 +574,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
     if constexpr (RT_SS_WG_SLICE) {                                                                                   \
         if (lane == lead_) ss_done[parity][wave] = lanes_here - (n);                                                  \
         const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];    \
-        out = (n) != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE;                                                        \
+        out = (n) != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);                                                        \
     } else out = (n) > stop_at;
 #define RT_SS_BOX_STEPS_HERE()                                                                                      \
     if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) { \
@@ -524,6 +614,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             } else {
                 w_best_t = k.best_t; w_best_prim = k.best_prim; w_best_scope = k.best_scope; w_scope = k.scope;
             }
+        }
         }
         /* 4. rank of every finished path in (key, wave, lane) order; index of every free lane in (wave, lane) order */
         const bool fin = !walking;

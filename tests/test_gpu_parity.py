@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import orc
+from dual import random_scene_pair
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -777,6 +778,42 @@ def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
         a, sa = ctx.render(64, 64, 6)
         assert sa["sorted"] & 512 and sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), (sah, near_far)
         ctx.close()
+    # sphere scenes: the pair walk in slices + the same reordering (bits 7 and 9); with the one-entry-per-step walk (V5, V2) as well
+    for sah in (False, True):
+        sc = rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5)
+        if sah:
+            sc.set_bvh_build(True)
+        ctx = gpu_ctx_factory(sc)
+        for W, H, spp, kw in ((96, 64, 6, {}), (300, 200, 3, {}), (17, 11, 5, {}), (96, 64, 24, dict(chunk=8, tile=(8, 8, 60, 40)))):
+            a, sa = ctx.render(W, H, spp, **kw)
+            b, sb = ctx.render(W, H, spp, unsorted=True, **kw)
+            assert sa["sorted"] & 512 and sa["sorted"] & 128 and not (sb["sorted"] & 512) and sb["sorted"] & 128, (sa["sorted"], sb["sorted"])
+            assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, W, H, spp, kw)
+            for kw2 in (dict(classic_walk=True), dict(variant=2)):
+                c_, sc2 = ctx.render(W, H, spp, **kw, **kw2)
+                assert sc2["sorted"] & 512 and not (sc2["sorted"] & 128), (kw2, sc2["sorted"])
+                assert sc2["segments"] == sb["segments"] and np.array_equal(c_, b, equal_nan=True), (sah, W, H, spp, kw, kw2)
+        cpu, sc_ = orc.flat_render(sc, 96, 64, 6, chunk=rt.default_chunk(96, 64, 6))
+        a, sa = ctx.render(96, 64, 6)
+        assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), sah
+        ctx.close()
+    # media with general boundaries (cornel_smoke's boxes under wrappers) through the forced stack walk, and random graphs: every
+    # stack variant a graph admits, reordered against plain against the CPU build of the core
+    cases = [(rt.Scene.reference(6, build_seed=1), 48, 48, 4)] + [(random_scene_pair(4100 + s_)[0], 56, 40, 3) for s_ in range(8)]
+    n_media = 0
+    for sc, W, H, spp in cases:
+        info = sc.info()
+        ctx = gpu_ctx_factory(sc)
+        cpu, sc_ = orc.flat_render(sc, W, H, spp, chunk=rt.default_chunk(W, H, spp))
+        for v in [3] + ([2] if not info["has_media"] else []) + ([5] if (not info["has_media"] and info["scope_depth"] == 0) else []):
+            a, sa = ctx.render(W, H, spp, variant=v)
+            b, sb = ctx.render(W, H, spp, variant=v, unsorted=True)
+            assert sa["variant"] == sb["variant"] == v and sa["sorted"] & 512 and not (sb["sorted"] & 512), (v, sa["sorted"], sb["sorted"])
+            assert sa["segments"] == sb["segments"] == sc_["segments"], (v, info)
+            assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, cpu, equal_nan=True), (v, info)
+        n_media += info["has_media"]
+        ctx.close()
+    assert n_media >= 2
 
 
 def test_precompiled_kernels_load_on_a_host_without_the_runtime_compiler(rt):
