@@ -372,7 +372,8 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
             L.f32 = true; L.jit = true; L.sorted = true; L.cached = false; L.variant = v; L.grid = c->jit32_grid; L.block = RT_SORT_BLOCK;
             return RT1W_OK;
         }
-        const bool sorted = v < 2 && !(p->flags & RT1W_UNSORTED);
+        const bool sorted = !(p->flags & RT1W_UNSORTED) && (v < 2 || !getenv("RT1W_NO_SLICE_SORT")); /* v >= 2: the slice-end reordering of the stack walks */
+        L.ss = sorted && v >= 2;
         int& g = c->f32_grid[v][sorted ? 1 : 0];
         if (!g) {
             hipDeviceProp_t prop;
@@ -491,7 +492,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = (L.sorted ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u) | (L.sphere_media ? 256u : 0u) | (L.ss ? 512u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = ((L.sorted && !L.ss) ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u) | (L.sphere_media ? 256u : 0u) | (L.ss ? 512u : 0u);
     }
     return RT1W_OK;
 }

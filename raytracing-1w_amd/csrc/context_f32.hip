@@ -49,10 +49,16 @@ template <class Cfg>
 __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_sorted_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
     rt_render_sorted_body<Cfg>(sc, f, partial, counters);
 }
+/* the stack-walk variants with the finished paths reordered at the end of every slice (rt_kernel_plain.h: rt_render_ss_body) */
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, RT_F32_WAVES(Cfg)) void rt_render_kernel_ss_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
+    rt_render_ss_body<Cfg, RT_STACK_CAP, 3>(sc, f, partial, counters);
+}
 typedef void (*kernel_t)(RtSceneView, RtFrame, rt_f64*, unsigned long long*);
 static kernel_t const g_plain[RT_N_VARIANTS] = {rt_render_kernel_f32<RtCfgV0>, rt_render_kernel_f32<RtCfgV1>, rt_render_kernel_f32<RtCfgV2>, rt_render_kernel_f32<RtCfgV3>,
                                                 nullptr, rt_render_kernel_f32<RtCfgV5>};
-static kernel_t const g_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted_f32<RtCfgV0>, rt_render_kernel_sorted_f32<RtCfgV1>, nullptr, nullptr, nullptr, nullptr};
+static kernel_t const g_sorted[RT_N_VARIANTS] = {rt_render_kernel_sorted_f32<RtCfgV0>, rt_render_kernel_sorted_f32<RtCfgV1>, rt_render_kernel_ss_f32<RtCfgV2>,
+                                                 rt_render_kernel_ss_f32<RtCfgV3>, nullptr, rt_render_kernel_ss_f32<RtCfgV5>};
 } // namespace rtf32
 
 #undef double

@@ -797,6 +797,14 @@ def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
         a, sa = ctx.render(96, 64, 6)
         assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), sah
         ctx.close()
+    # the f32 builds of the stack-walk kernels reorder the same way: within f32 mode the frame does not depend on it, bit for bit
+    for arm, aspect, W, H, spp in ((7, 1.0, 96, 96, 4), (0, 1.5, 96, 64, 4)):
+        ctx = gpu_ctx_factory(rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect))
+        a, sa = ctx.render(W, H, spp, f32=True)
+        b, sb = ctx.render(W, H, spp, f32=True, unsorted=True)
+        assert sa["sorted"] & 32 and sa["sorted"] & 512 and sb["sorted"] & 32 and not (sb["sorted"] & 512), (sa["sorted"], sb["sorted"])
+        assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), arm
+        ctx.close()
     # media with general boundaries (cornel_smoke's boxes under wrappers) through the forced stack walk, and random graphs: every
     # stack variant a graph admits, reordered against plain against the CPU build of the core
     cases = [(rt.Scene.reference(6, build_seed=1), 48, 48, 4)] + [(random_scene_pair(4100 + s_)[0], 56, 40, 3) for s_ in range(8)]
