@@ -267,7 +267,7 @@ def kernel_name(st):
     if flags & 4:
         return "rt_jit_sorted"
     if flags & 128:
-        return "rt_render_kernel_pw<V%d>" % st["variant"]
+        return ("rt_render_kernel_pw_ss<V%d>" if (flags & 512) else "rt_render_kernel_pw<V%d>") % st["variant"]
     if flags & 512:
         return "rt_render_kernel_ss<V%d, sphere media>" % st["variant"]
     if flags & 256:
