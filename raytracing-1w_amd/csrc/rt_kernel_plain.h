@@ -380,6 +380,12 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
  * 56: 925 (the plain kernel: 878) */
 #define RT_SS_IDLE(Cfg) (Cfg::media ? 40 : 48)
 #endif
+#ifndef RT_SS_BOX_STEPS
+/* box-only steps per round of these kernels: with the slice ended for the whole workgroup a shorter round pays (the stop is noticed sooner).
+ * final_scene 800x800x100, kernel Mpaths/s: register form (V3) 4: 307-309, 3: 314-319, 2: 312-318; one-step form (V4, SAH + near-far) 4: 331,
+ * 3: 337, 2: 346 */
+#define RT_SS_BOX_STEPS(Cfg) (Cfg::media ? (Cfg::ordered ? 2 : 3) : 0)
+#endif
 #ifndef RT_SS_WG_SLICE
 #define RT_SS_WG_SLICE 1 /* the slice ends for the whole workgroup at once: every wave publishes how many of its walks have ended and all stop
                             when the workgroup's total reaches 4 x RT_SS_IDLE -- the waves then reach the sort's barrier within a round of each other.
@@ -577,11 +583,11 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         out = (n) != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);                                                        \
     } else out = (n) > stop_at;
 #define RT_SS_BOX_STEPS_HERE()                                                                                      \
-    if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) { \
-        rt_walk_box_run<Cfg, RT_SLICE_BOX_STEPS(Cfg)>(ns, k, stk);                                                  \
-    } else if constexpr (RT_SLICE_BOX_STEPS(Cfg) > 0) {                                                             \
+    if constexpr (RT_SS_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) { \
+        rt_walk_box_run<Cfg, RT_SS_BOX_STEPS(Cfg)>(ns, k, stk);                                                  \
+    } else if constexpr (RT_SS_BOX_STEPS(Cfg) > 0) {                                                             \
         bool between_boxes = true;                                                                                  \
-        for (int extra = 0; extra < RT_SLICE_BOX_STEPS(Cfg); ++extra)                                               \
+        for (int extra = 0; extra < RT_SS_BOX_STEPS(Cfg); ++extra)                                               \
             if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);          \
     }
             for (;;) {

@@ -19,7 +19,7 @@ ctx = rt.Context(sc, 0)
 os.environ.pop("RT1W_NO_SLICE_SORT", None)
 ctx.render(W, H, 4)
 ref = None
-for rep in range(2):
+for rep in range(3):
     for mode in ("plain", "slice-sorted"):
         if mode == "plain":
             os.environ["RT1W_NO_SLICE_SORT"] = "1"
