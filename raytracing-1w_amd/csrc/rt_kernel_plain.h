@@ -386,6 +386,13 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
  * 3: 337, 2: 346 */
 #define RT_SS_BOX_STEPS(Cfg) (Cfg::media ? (Cfg::ordered ? 2 : 3) : 0)
 #endif
+/* The other waves' counters are read while they write them -- a hint, not a synchronisation: a stale value only delays the stop by a
+ * round, and the loop ends by itself when the wave's own walks are over.  The compiler-level fence (no instruction) keeps the four
+ * loads from being held in registers across rounds; they still go out as one LDS load (declaring the counters volatile instead: four
+ * separate loads in program order, -3 %).  By the cycle stamps the waves still spend 18 % of their time at the sort's barrier
+ * (final_scene; 10 % on random_scene): measured and NOT the cure -- ending the slice as soon as any wave has no walk left (302 against
+ * 304 Mpaths/s), or only after every wave has passed 2 / 4 / 8 checks in it (312-318 against 316-318); profiles/r03_slice_sort.txt. */
+#define RT_SS_FENCE_HERE() asm volatile("" ::: "memory")
 #ifndef RT_SS_WG_SLICE
 #define RT_SS_WG_SLICE 1 /* the slice ends for the whole workgroup at once: every wave publishes how many of its walks have ended and all stop
                             when the workgroup's total reaches 4 x RT_SS_IDLE -- the waves then reach the sort's barrier within a round of each other.
@@ -439,7 +446,14 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
     bool walking = false;
     double w_best_t = RT_INF;
     uint32_t w_best_prim = RT_NONE, w_best_scope = RT_NONE, w_scope = RT_NONE;
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 16; ++k) rt_stamp_acc[threadIdx.x >> 6][k] = 0;
+        rt_stamp_last[threadIdx.x >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     for (;;) {
+        RT_STAMP(6);
         /* 1. regeneration: next sample of the lane's item, or a new item (lanes between two walks only) */
         if (!walking && !path.alive && !retired) {
             const uint32_t s_end = chunk * f.chunk + f.chunk < f.spp ? chunk * f.chunk + f.chunk : f.spp;
@@ -471,6 +485,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             if (!have) retired = true;
             else rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
         }
+        RT_STAMP(1);
         RtTrace tr;
         tr.t = RT_R(0.0); tr.prim = RT_NONE; tr.scope = RT_NONE; tr.cls = retired ? RT_CLS_IDLE : RT_CLS_TERMINAL;
         uint32_t key = retired ? 6u : 5u;
@@ -504,6 +519,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
                         const uint32_t n_ = (uint32_t)__popcll(__ballot(more));
                         if constexpr (RT_SS_WG_SLICE) {
                             if (lane == lead_) ss_done[parity][wave] = lanes_here - n_;
+                            RT_SS_FENCE_HERE();
                             const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];
                             on_ = n_ != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);
                         } else on_ = n_ > stop_at;
@@ -579,6 +595,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
 #define RT_SS_GOES_ON(n, out)                                                                                         \
     if constexpr (RT_SS_WG_SLICE) {                                                                                   \
         if (lane == lead_) ss_done[parity][wave] = lanes_here - (n);                                                  \
+        RT_SS_FENCE_HERE();                                                                                           \
         const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];    \
         out = (n) != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);                                                        \
     } else out = (n) > stop_at;
@@ -622,6 +639,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             }
         }
         }
+        RT_STAMP(2);
         /* 4. rank of every finished path in (key, wave, lane) order; index of every free lane in (wave, lane) order */
         const bool fin = !walking;
         uint32_t my_rank = 0;
@@ -634,7 +652,9 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         const unsigned long long free_m = __ballot(fin);
         uint32_t q = lane_prefix(free_m);
         if (lane == 0u) cnt[wave][RT_SS_KEYS] = (uint32_t)__popcll(free_m);
+        RT_STAMP(8);
         __syncthreads();
+        RT_STAMP(9);
         if constexpr (RT_SS_WG_SLICE) { if (lane == 0u) ss_done[parity ^ 1u][wave] = 0u; parity ^= 1u; } /* the next slice's counters: nobody reads them before the barriers below */
         uint32_t dest = my_rank, idle_total = 0;
 #pragma unroll
@@ -699,6 +719,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
 #undef RT_UP2
             }
         }
+        RT_STAMP(7); /* diagnostic builds: bucket 7 = the exchange here */
         /* 6. shading, coherent within a wave after the sort */
         if (fin && !retired) {
             rt_path_shade<Cfg>(sc, path, tr);
@@ -710,6 +731,10 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         }
     }
     if (segs) atomicAdd(&counters[1], segs);
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 16; ++k) atomicAdd(&g_stamp_total[k], rt_stamp_acc[threadIdx.x >> 6][k]);
+#endif
 }
 
 #endif

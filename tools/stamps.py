@@ -20,7 +20,8 @@ names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+t
 if walk:
     names[8:14] = ["walk: pop + fetch + class", "walk: box", "walk: leaf", "walk: wrapper entry", "walk: wrapper exit", "walk: medium (outside its boundary walks)"]
     names[2] = "walk: loop control, slice votes"
-for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), (400, 400, 32)) for a in args):
+big = tuple(int(x) for x in os.environ.get("RT1W_STAMPS_SIZE", "400,400,32").split(","))  # e.g. RT1W_STAMPS_SIZE=800,800,48: enough work items to keep the tail small
+for arm, (W, H, spp) in ((5, (600, 600, 100)),) + tuple((int(a), big) for a in args):
     sc = rt.Scene.reference(arm)
     ctx = rt.Context(sc, 0)
     if jit:
