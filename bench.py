@@ -269,7 +269,7 @@ def kernel_name(st):
     if flags & 128:
         return ("rt_render_kernel_pw_ss<V%d>" if (flags & 512) else "rt_render_kernel_pw<V%d>") % st["variant"]
     if flags & 512:
-        return "rt_render_kernel_ss<V%d, sphere media>" % st["variant"]
+        return ("rt_render_kernel_ss<V%d, sphere media>" if (flags & 256) else "rt_render_kernel_ss<V%d>") % st["variant"]
     if flags & 256:
         return "rt_render_kernel<V%d, sphere media>" % st["variant"]
     return ("rt_render_kernel_sorted<V%d>" if (flags & 1) else "rt_render_kernel<V%d>") % st["variant"]

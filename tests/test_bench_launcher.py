@@ -92,3 +92,18 @@ def test_stored_pmc_is_attached_only_to_the_kernel_it_was_measured_on(tmp_path, 
     assert r["valu_lane_issue_frac"] == 0.4 and r["traffic"] is None
     r = bench.roofline_block("c4", st, 1.0, 100, "abc", spp=1000)
     assert r["valu_lane_issue_frac"] is None and r["traffic"] is None
+
+
+def test_kernel_names_follow_the_stats_flags():
+    """bench.py names the kernel a render ran from rt1w_stats (variant + the bits of `sorted`, include/rt1w.h): the stored PMC is
+    matched by that name, so the kernels with the slice-end reordering (bit 9) must not be taken for the plain ones"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.kernel_name({"sorted": 4 | 1, "variant": 0}) == "rt_jit_sorted"
+    assert bench.kernel_name({"sorted": 1, "variant": 1}) == "rt_render_kernel_sorted<V1>"
+    assert bench.kernel_name({"sorted": 0, "variant": 2}) == "rt_render_kernel<V2>"
+    assert bench.kernel_name({"sorted": 128, "variant": 5}) == "rt_render_kernel_pw<V5>"
+    assert bench.kernel_name({"sorted": 128 | 512, "variant": 5}) == "rt_render_kernel_pw_ss<V5>"
+    assert bench.kernel_name({"sorted": 256, "variant": 3}) == "rt_render_kernel<V3, sphere media>"
+    assert bench.kernel_name({"sorted": 256 | 512, "variant": 4}) == "rt_render_kernel_ss<V4, sphere media>"
+    assert bench.kernel_name({"sorted": 512, "variant": 2}) == "rt_render_kernel_ss<V2>"
