@@ -17,4 +17,5 @@ timeout -k 10 300 python3 bench.py --workload c2 --steps 3 > $O/bench_c2.json 2>
 echo "== stored PMC"; tools/bench_pmc.sh > $O/bench_pmc.log 2>&1; cp gpurun_out/bench_pmc/pmc_summary.json $O/ 2>/dev/null
 echo "== full sizes"; timeout -k 10 300 python3 tools/full_size.py C2 C4 C5 > $O/full_size.txt 2>&1
 echo "== configs"; timeout -k 10 500 python3 tools/configs_bench.py > $O/configs.txt 2>&1
+echo "== reordering kernels against the plain ones, soak"; (timeout -k 10 200 python3 tools/ss_ab.py 7 800 800 100; timeout -k 10 200 python3 tools/ss_ab.py 0 1200 800 100; timeout -k 10 300 python3 tools/ss_soak.py 8) > $O/slice_sort.txt 2>&1
 find $O -name "*kernel_stats.csv" | head; echo done
