@@ -148,6 +148,13 @@ int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode);
  * contexts; RT1W_ERR_UNSUPPORTED (scene unchanged) if the rebuilt trees need a deeper traversal stack than the kernels have. */
 #define RT1W_BVH_REFERENCE 0u
 #define RT1W_BVH_SAH 1u
+/* RT1W_BVH_BEST_AXIS: `BVHNode::new` as written -- the reference's sort key, stable order, median split and one- / two-object shapes
+ * (src/bvh.rs:60-100) -- with the axis of src/bvh.rs:84 CHOSEN (the one whose median split has the lowest area(L)*|L| + area(R)*|R|)
+ * instead of drawn from the entropy-seeded generator of src/main.rs:803.  Every axis sequence is a tree some run of the reference
+ * builds, so unlike RT1W_BVH_SAH this is a tree the reference itself can produce; nested `BVHNode::new` calls stay separate BVHs.
+ * In its topology stream (rt1w_scene_get_bvh_topology) a leaf's number is the object's position in the list its `BVHNode::new` call
+ * received (src/bvh.rs:55), and a BVHNode that is an object of another BVH is a leaf whose own tree follows its number. */
+#define RT1W_BVH_BEST_AXIS 2u
 int rt1w_scene_set_bvh_build(rt1w_scene* s, uint32_t mode);
 /* The trees RT1W_BVH_SAH built in place of `BVHNode::new` (src/bvh.rs:54-103), written down so that they can be checked from
  * outside (tests feed them to the literal oracle, which then runs `BVHNode::hit` src/bvh.rs:25-50 over the same trees).

@@ -604,6 +604,8 @@ struct BVHNode : Hittable {
     HBox left, right; /* BVHChild::One(obj) -> left only */
     AABB aabb;
     Float time0 = 0.0, time1 = 1.0; /* what `new` was called with (kept for orc_scene_apply_topology only) */
+    bool call_root = false;         /* made by a `BVHNode::new` call of a scene builder, not by the recursion inside one (same use) */
+    std::vector<const Hittable*> call_order; /* call_root: the objects in the order that call received them (same use) */
     bool bounding_box(Float, Float, AABB& out) const override { out = aabb; return true; } /* :21-23 */
     bool hit(const Ray& ray, Float t_min, Float t_max, MyRng& rng, HitRecord& out) const override { /* :25-50 */
         if (!aabb.hit(ray, t_min, t_max)) return false;
@@ -617,10 +619,37 @@ struct BVHNode : Hittable {
         }
         return right->hit(ray, t_min, t_max, rng, out);
     }
+    /* orc_set_bvh_axis_rule(1): the axis of bvh.rs:84 is not the one drawn but the one whose median split (bvh.rs:85-87) has the lowest
+     * area(L)*|L| + area(R)*|R| (ties: the lower axis) -- one of the trees the reference builds with non-zero probability.  This is
+     * the oracle's own statement of the product's opt-in RT1W_BVH_BEST_AXIS (include/rt1w.h); the draw is still made so that what the
+     * scene builders draw afterwards does not move. */
+    static int g_bvh_axis_rule;
+    static Float half_area(const AABB& b) { const V3 e = b.maximum - b.minimum; return e.x * e.y + e.y * e.z + e.z * e.x; }
+    static uint32_t best_axis(const std::vector<HBox>& objects, Float time0, Float time1) {
+        const size_t len = objects.size();
+        uint32_t best = 0;
+        Float best_cost = 0;
+        for (uint32_t axis = 0; axis < 3; ++axis) {
+            std::vector<std::pair<uint64_t, size_t>> keyed;
+            std::vector<AABB> boxes(len);
+            for (size_t i = 0; i < len; ++i) {
+                if (!objects[i]->bounding_box(time0, time1, boxes[i])) throw std::string("unwrap on None");
+                keyed.push_back({float_ord_key(rt_get(boxes[i].minimum, (int)axis)), i});
+            }
+            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, size_t>& a, const std::pair<uint64_t, size_t>& b) { return a.first < b.first; });
+            AABB l = boxes[keyed[0].second], r = boxes[keyed[len / 2].second];
+            for (size_t i = 1; i < len / 2; ++i) l = surrounding_box(l, boxes[keyed[i].second]);
+            for (size_t i = len / 2 + 1; i < len; ++i) r = surrounding_box(r, boxes[keyed[i].second]);
+            const Float cost = half_area(l) * (Float)(len / 2) + half_area(r) * (Float)(len - len / 2);
+            if (axis == 0 || cost < best_cost) { best_cost = cost; best = axis; }
+        }
+        return best;
+    }
     /* BVHNode::new bvh.rs:54-103; throws std::string on the reference's panics */
-    static std::unique_ptr<BVHNode> make(std::vector<HBox> objects, Float time0, Float time1, MyRng& rng) {
+    static std::unique_ptr<BVHNode> make(std::vector<HBox> objects, Float time0, Float time1, MyRng& rng, bool top = true) {
         std::unique_ptr<BVHNode> n(new BVHNode());
-        n->time0 = time0; n->time1 = time1;
+        n->time0 = time0; n->time1 = time1; n->call_root = top;
+        if (top) for (const HBox& o : objects) n->call_order.push_back(o.get());
         size_t len = objects.size();
         if (len == 0) throw std::string("objects mut not be empty");
         if (len == 1) {
@@ -636,6 +665,7 @@ struct BVHNode : Hittable {
             n->left = std::move(left); n->right = std::move(right);
         } else {
             uint32_t axis = rt_gen_below(rng, 3u); /* rng.gen_range(0..=2) */
+            if (g_bvh_axis_rule == 1) axis = best_axis(objects, time0, time1); /* the draw is made and overruled: see orc_set_bvh_axis_rule */
             std::vector<std::pair<uint64_t, size_t>> keyed;
             for (size_t i = 0; i < len; ++i) {
                 AABB b;
@@ -645,14 +675,16 @@ struct BVHNode : Hittable {
             std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, size_t>& a, const std::pair<uint64_t, size_t>& b) { return a.first < b.first; });
             std::vector<HBox> l, r;
             for (size_t i = 0; i < len; ++i) (i < len / 2 ? l : r).push_back(std::move(objects[keyed[i].second]));
-            std::unique_ptr<BVHNode> ln = make(std::move(l), time0, time1, rng);
-            std::unique_ptr<BVHNode> rn = make(std::move(r), time0, time1, rng);
+            std::unique_ptr<BVHNode> ln = make(std::move(l), time0, time1, rng, false);
+            std::unique_ptr<BVHNode> rn = make(std::move(r), time0, time1, rng, false);
             n->aabb = surrounding_box(ln->aabb, rn->aabb);
             n->left = std::move(ln); n->right = std::move(rn);
         }
         return n;
     }
 };
+
+int BVHNode::g_bvh_axis_rule = 0;
 
 /* ---- aabox.rs ---- */
 struct AABox : Hittable {
@@ -1288,18 +1320,27 @@ orc_scene* orcb_finish(orc_builder* b) {
  * `BVHNode::hit` (bvh.rs:25-50) above walks them -- nothing of the product's traversal is involved. */
 struct TopoReader {
     const int32_t* p; uint64_t n, pos; bool ok;
+    bool merge; /* a BVHNode that is itself an object of a BVH: its leaves join the parent's (RT1W_BVH_SAH) or it stays a BVH of its own
+                   (RT1W_BVH_BEST_AXIS: every `BVHNode::new` call of the scene is rebuilt separately) */
     int32_t next() { if (pos >= n) { ok = false; return 0; } return p[pos++]; }
 };
-static size_t count_leaves(const Hittable* h) {
+static bool topo_inner(const BVHNode* b, bool top, bool merge) { return b && (top || merge || !b->call_root); }
+static size_t count_leaves(const Hittable* h, bool top, bool merge) {
     const BVHNode* b = dynamic_cast<const BVHNode*>(h);
-    if (!b) return 1;
-    return count_leaves(b->left.get()) + (b->right ? count_leaves(b->right.get()) : 0);
+    if (!topo_inner(b, top, merge)) return 1;
+    return count_leaves(b->left.get(), false, merge) + (b->right ? count_leaves(b->right.get(), false, merge) : 0);
 }
-static void take_leaves(HBox& h, std::vector<HBox>& out) { /* left to right through nested BVHNodes */
+static void take_leaves(HBox& h, std::vector<HBox>& out, bool top, bool merge) { /* left to right */
     BVHNode* b = dynamic_cast<BVHNode*>(h.get());
-    if (!b) { out.push_back(std::move(h)); return; }
-    take_leaves(b->left, out);
-    if (b->right) take_leaves(b->right, out);
+    if (!topo_inner(b, top, merge)) { out.push_back(std::move(h)); return; }
+    take_leaves(b->left, out, false, merge);
+    if (b->right) take_leaves(b->right, out, false, merge);
+    if (top && !merge && b->call_order.size() == out.size()) { /* RT1W_BVH_BEST_AXIS numbers a call's objects in the order it received them */
+        std::vector<HBox> ordered;
+        for (const Hittable* want : b->call_order)
+            for (HBox& o : out) if (o && o.get() == want) { ordered.push_back(std::move(o)); break; }
+        if (ordered.size() == out.size()) out = std::move(ordered);
+    }
 }
 static void retopo_any(HBox& h, TopoReader& r);
 static HBox build_from_topology(std::vector<HBox>& leaves, TopoReader& r, Float t0, Float t1) {
@@ -1331,14 +1372,21 @@ static HBox build_from_topology(std::vector<HBox>& leaves, TopoReader& r, Float 
 static void retopo_any(HBox& h, TopoReader& r) {
     if (!r.ok || !h) return;
     if (BVHNode* b = dynamic_cast<BVHNode*>(h.get())) {
-        if (count_leaves(b) >= 2) {
+        if (count_leaves(b, true, r.merge) >= 2) {
             const Float t0 = b->time0, t1 = b->time1;
             std::vector<HBox> leaves;
-            take_leaves(h, leaves);
+            take_leaves(h, leaves, true, r.merge);
+            std::vector<const Hittable*> order;
+            for (const HBox& l : leaves) order.push_back(l.get());
             h = build_from_topology(leaves, r, t0, t1);
+            if (BVHNode* nb = dynamic_cast<BVHNode*>(h.get())) { nb->call_root = true; nb->call_order = order; }
             for (const HBox& l : leaves) if (l) r.ok = false; /* every leaf must have been placed */
         } else { /* a chain of BVHChild::One down to a single object: kept as built */
-            while (BVHNode* c = dynamic_cast<BVHNode*>(b->left.get())) b = c;
+            for (;;) {
+                BVHNode* c = dynamic_cast<BVHNode*>(b->left.get());
+                if (!c || (!r.merge && c->call_root)) break;
+                b = c;
+            }
             retopo_any(b->left, r);
         }
         return;
@@ -1354,8 +1402,13 @@ static void retopo_any(HBox& h, TopoReader& r) {
     else if (ConstantMedium* m = dynamic_cast<ConstantMedium*>(h.get())) retopo_any(m->boundary, r);
 }
 /* 0 = done; -1 = the stream does not fit this scene (the scene is unusable afterwards) */
-int orc_scene_apply_topology(orc_scene* o, const int32_t* topo, uint64_t n) {
-    TopoReader r{topo, n, 0, true};
+/* merge_nested: 1 for the streams of RT1W_BVH_SAH, 0 for those of RT1W_BVH_BEST_AXIS (include/rt1w.h) */
+int orc_scene_apply_topology_mode(orc_scene* o, const int32_t* topo, uint64_t n, int merge_nested);
+/* 0 (default): the split axis of BVHNode::new is the one drawn (bvh.rs:84); 1: see BVHNode::best_axis.  Applies to scenes built afterwards. */
+void orc_set_bvh_axis_rule(int rule) { BVHNode::g_bvh_axis_rule = rule; }
+int orc_scene_apply_topology(orc_scene* o, const int32_t* topo, uint64_t n) { return orc_scene_apply_topology_mode(o, topo, n, 1); }
+int orc_scene_apply_topology_mode(orc_scene* o, const int32_t* topo, uint64_t n, int merge_nested) {
+    TopoReader r{topo, n, 0, true, merge_nested != 0};
     HBox world(o->s.world.release());
     retopo_any(world, r);
     o->s.world.reset(dynamic_cast<BVHNode*>(world.get()));

@@ -296,10 +296,13 @@ class Scene:
 
     def commit(self): _ck(_lib.rt1w_scene_commit(self._h))
 
-    def set_bvh_build(self, sah):
-        """Opt-in BVH build (rt1w_scene_set_bvh_build): False = BVHNode::new as written (random axis, median split; default),
-        True = the trees rebuilt by surface-area heuristic (statistically the same frames, not bit for bit).  Returns self."""
-        _ck(_lib.rt1w_scene_set_bvh_build(self._h, 1 if sah else 0))
+    def set_bvh_build(self, mode):
+        """Opt-in BVH build (rt1w_scene_set_bvh_build): False / 0 = BVHNode::new as written (random axis, median split; default),
+        True / 1 / "sah" = the trees rebuilt by surface-area heuristic (statistically the same frames, not bit for bit),
+        2 / "best_axis" = BVHNode::new as written with the axis of bvh.rs:84 chosen by the lowest cost of its median split instead of
+        drawn (a tree the reference itself can build).  Returns self."""
+        mode = {"reference": 0, "sah": 1, "best_axis": 2}.get(mode, mode)
+        _ck(_lib.rt1w_scene_set_bvh_build(self._h, int(mode)))
         return self
 
     def set_walk_order(self, near_far):
@@ -309,7 +312,7 @@ class Scene:
         return self
 
     def bvh_topology(self):
-        """The trees of the opt-in SAH build as one int32 stream (rt1w_scene_get_bvh_topology); empty for the reference's build."""
+        """The trees of the opt-in SAH / best-axis builds as one int32 stream (rt1w_scene_get_bvh_topology); empty for the reference's build."""
         n = int(_lib.rt1w_scene_get_bvh_topology(self._h, None, 0))
         _ck(n)
         out = np.zeros(max(n, 1), dtype=np.int32)

@@ -73,10 +73,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss(
 /* the same for sphere scenes: the pair walk in slices + the reordering of the finished paths (RT_PW_SS_STACK entries per lane instead of
  * RT_PW_STACK: what leaves room for the exchange buffer next to the pair walk's stacks and queues at three workgroups per CU) */
 #define RT_PW_SS_STACK 12
+#ifndef RT_PW_SS_PARTS
+#define RT_PW_SS_PARTS 3 /* rounds of the exchange */
+#endif
+#ifndef RT_SS_CAP
+#define RT_SS_CAP RT_STACK_CAP /* stack entries per lane of the stack-walk kernels that reorder (experiments: 16 for four workgroups per CU) */
+#endif
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_pw_ss(RtSceneView sc, RtPwView pw, RtFrame f, double* __restrict__ partial,
                                                                               unsigned long long* __restrict__ counters) {
-    rt_render_ss_body<Cfg, RT_PW_SS_STACK, 3, true>(sc, f, partial, counters, &pw);
+    rt_render_ss_body<Cfg, RT_PW_SS_STACK, RT_PW_SS_PARTS, true>(sc, f, partial, counters, &pw);
 }
 
 /* the reordering kernel proper (rt_kernel_sorted.h) */
@@ -227,8 +233,8 @@ static render_kernel_t const g_kernels_sphere_media[RT_N_VARIANTS] = {nullptr, n
 /* the stack-walk kernels with the finished paths reordered across the workgroup at the end of every slice (rt_render_ss_body): the default
  * for the scenes they cover; [1] = the sphere-media builds */
 static render_kernel_t const g_kernels_ss[2][RT_N_VARIANTS] = {
-    {nullptr, nullptr, rt_render_kernel_ss<RtCfgV2, RT_STACK_CAP, 3>, rt_render_kernel_ss<RtCfgV3, RT_STACK_CAP, 3>, nullptr, rt_render_kernel_ss<RtCfgV5, RT_STACK_CAP, 3>},
-    {nullptr, nullptr, nullptr, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV3>, RT_STACK_CAP, 3>, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV4>, RT_STACK_CAP, 3>, nullptr}};
+    {nullptr, nullptr, rt_render_kernel_ss<RtCfgV2, RT_SS_CAP, 3>, rt_render_kernel_ss<RtCfgV3, RT_SS_CAP, 3>, nullptr, rt_render_kernel_ss<RtCfgV5, RT_SS_CAP, 3>},
+    {nullptr, nullptr, nullptr, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV3>, RT_SS_CAP, 3>, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV4>, RT_SS_CAP, 3>, nullptr}};
 /* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
  * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
 static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr, rt_render_kernel<RtCfgV5, true>};

@@ -1244,7 +1244,11 @@ RT_HD double rt_reflectance(double cosine, double ref_idx) {                  /*
 /* --------------------------------------------------------------- camera -- */
 
 /* main.rs:964-971 + Camera::get_ray camera.rs:61-73 */
+RT_HD void rt_path_begin_cam(const RtCamera& c, const RtFrame& f, uint32_t i, uint32_t j,
+                         uint32_t sample, RtPath& p);
 RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, uint32_t j,
+                         uint32_t sample, RtPath& p) { rt_path_begin_cam(sc.camera, f, i, j, sample, p); }
+RT_HD void rt_path_begin_cam(const RtCamera& c, const RtFrame& f, uint32_t i, uint32_t j,
                          uint32_t sample, RtPath& p) {
 #if defined(RT_RNG_REFSTREAM)
     /* main.rs:964-967: the pixel's stream is seeded once, before its sample loop, and every sample draws on from where
@@ -1256,7 +1260,6 @@ RT_HD void rt_path_begin(const RtSceneView& sc, const RtFrame& f, uint32_t i, ui
     rt_rng_reserve(p.rng, 4u);
     double u = ((double)i + rt_take_f64(p.rng)) / (double)(f.width - 1u);
     double v = ((double)j + rt_take_f64(p.rng)) / (double)(f.height - 1u);
-    const RtCamera& c = sc.camera;
     RtV3 rd = c.lens_radius * rt_random_in_unit_disk(p.rng);
     RtV3 offset = c.u * rd.x + c.v * rd.y;
     p.ray.o = c.origin + offset;

@@ -483,7 +483,19 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
                 }
             }
             if (!have) retired = true;
-            else rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
+            else {
+                /* the camera block is read where it is used, by scalar loads from the kernel-argument segment: held across the loop its
+                 * 24 doubles cost 48 SGPRs the walk needs (they were spilled to VGPR lanes and to scratch) */
+                typedef const __attribute__((address_space(4))) double* kd_t;
+                kd_t kc = (kd_t)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RtSceneView, camera));
+                asm volatile("" : "+s"(kc));
+                RtCamera cam;
+                cam.origin = rt_v3(kc[0], kc[1], kc[2]); cam.lower_left_corner = rt_v3(kc[3], kc[4], kc[5]);
+                cam.horizontal = rt_v3(kc[6], kc[7], kc[8]); cam.vertical = rt_v3(kc[9], kc[10], kc[11]);
+                cam.u = rt_v3(kc[12], kc[13], kc[14]); cam.v = rt_v3(kc[15], kc[16], kc[17]); cam.w = rt_v3(kc[18], kc[19], kc[20]);
+                cam.lens_radius = kc[21]; cam.time0 = kc[22]; cam.time1 = kc[23];
+                rt_path_begin_cam(cam, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
+            }
         }
         RT_STAMP(1);
         RtTrace tr;
@@ -722,10 +734,10 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         RT_STAMP(7); /* diagnostic builds: bucket 7 = the exchange here */
         /* 6. shading, coherent within a wave after the sort */
         if (fin && !retired) {
+            path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0)); /* a path's radiance is written by its terminal only (rt_path_shade): nothing to carry */
             rt_path_shade<Cfg>(sc, path, tr);
             if (!path.alive) {
                 sum = rt_v3d_add(sum, path.radiance);
-                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
                 ++s;
             }
         }

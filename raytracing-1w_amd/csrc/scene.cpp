@@ -236,6 +236,71 @@ struct Flattener {
         return idx;
     }
 
+    /* ---- opt-in RT1W_BVH_BEST_AXIS: `BVHNode::new` as written (bvh.rs:54-103) with ONE thing chosen instead of drawn ----
+     * The reference draws the split axis of every node from an entropy-seeded generator (bvh.rs:84, main.rs:803), sorts the objects
+     * stably by their box minimum on it (float-ord, bvh.rs:85-86) and splits at len/2 (bvh.rs:87); one and two objects get the shapes of
+     * bvh.rs:63-79.  Every axis sequence is a tree some run of the reference builds.  Here the axis of a node is the one whose
+     * median split has the lowest area(L)*|L| + area(R)*|R| (ties: the lower axis); everything else -- the sort key, the stable
+     * order, the split position, left = last of two, the boxes (surrounding_box of the children) -- is the reference's rule on the
+     * objects in the order the host handed them to this `BVHNode::new` call.  Nested `BVHNode::new` calls stay separate BVHs. */
+    struct BaItem { int id; AABB box; int32_t orig; /* position in the call's own object list: the leaf's number in the topology stream */ };
+    static AABB box_of(const std::vector<BaItem>& v, size_t lo, size_t hi) {
+        AABB b = v[lo].box;
+        for (size_t i = lo + 1; i < hi; ++i) b = surrounding_box(b, v[i].box);
+        return b;
+    }
+    uint32_t emit_best_axis(std::vector<BaItem> objs, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary, uint32_t* need, AABB* box_out) {
+        const size_t len = objs.size();
+        const uint32_t idx = (uint32_t)out.size();
+        if (len == 1) { /* BVHChild::One, aabb = the object's own box (bvh.rs:63-70) */
+            if (topo) { topo->push_back(-2); topo->push_back(objs[0].orig); }
+            RtNode n = blank(RT_BVH1);
+            const AABB& box = objs[0].box;
+            n.d[0] = box.minimum.x; n.d[1] = box.minimum.y; n.d[2] = box.minimum.z;
+            n.d[3] = box.maximum.x; n.d[4] = box.maximum.y; n.d[5] = box.maximum.z;
+            out.push_back(n);
+            uint32_t na = 0;
+            const uint32_t a = emit(objs[0].id, parent_scope, scope_depth, in_boundary, &na);
+            out[idx].a = a;
+            *need = std::max(2u, na);
+            *box_out = box;
+            return idx;
+        }
+        if (topo) topo->push_back(-1);
+        out.push_back(blank(RT_BVH2));
+        uint32_t na = 0, nb = 0, a, b;
+        AABB lb, rb;
+        if (len == 2) { /* BVHChild::Two(objects.pop(), objects.pop()): the LAST object is the left child (bvh.rs:71-79) */
+            lb = objs[1].box; rb = objs[0].box;
+            if (topo) topo->push_back(objs[1].orig);
+            a = emit(objs[1].id, parent_scope, scope_depth, in_boundary, &na);
+            if (topo) topo->push_back(objs[0].orig);
+            b = emit(objs[0].id, parent_scope, scope_depth, in_boundary, &nb);
+        } else {
+            std::vector<BaItem> best_order;
+            double best = RT_INF;
+            for (int axis = 0; axis < 3; ++axis) {
+                std::vector<BaItem> v = objs;
+                std::stable_sort(v.begin(), v.end(), [axis](const BaItem& x, const BaItem& y) {
+                    return float_ord_key(rt_get(x.box.minimum, axis)) < float_ord_key(rt_get(y.box.minimum, axis));
+                });
+                const double cost = Flattener::half_area(box_of(v, 0, len / 2)) * (double)(len / 2) + Flattener::half_area(box_of(v, len / 2, len)) * (double)(len - len / 2);
+                if (best_order.empty() || cost < best) { best = cost; best_order = v; }
+            }
+            std::vector<BaItem> l(best_order.begin(), best_order.begin() + (long)(len / 2)), r(best_order.begin() + (long)(len / 2), best_order.end());
+            a = emit_best_axis(l, parent_scope, scope_depth, in_boundary, &na, &lb);
+            b = emit_best_axis(r, parent_scope, scope_depth, in_boundary, &nb, &rb);
+        }
+        const AABB box = surrounding_box(lb, rb);
+        RtNode& n = out[idx];
+        n.d[0] = box.minimum.x; n.d[1] = box.minimum.y; n.d[2] = box.minimum.z;
+        n.d[3] = box.maximum.x; n.d[4] = box.maximum.y; n.d[5] = box.maximum.z;
+        n.a = a; n.b = b;
+        *need = std::max(2u, std::max(1u + na, nb));
+        *box_out = box;
+        return idx;
+    }
+
     /* returns node index; *need = stack entries in use beyond the popped entry of
      * this node while its subtree is processed */
     uint32_t emit(int id, uint32_t parent_scope, uint32_t scope_depth, bool in_boundary, uint32_t* need) {
@@ -260,6 +325,22 @@ struct Flattener {
                     std::vector<SahItem> items;
                     if (collect_leaves(id, h.d[0], h.d[1], items) && items.size() >= 2)
                         return emit_sah(items, 0, items.size(), parent_scope, scope_depth, in_boundary, need);
+                }
+                if (s.bvh_build == RT1W_BVH_BEST_AXIS) {
+                    const auto call = s.bvh_calls.find(id);
+                    if (call != s.bvh_calls.end() && call->second.size() >= 2) {
+                        std::vector<BaItem> objs;
+                        bool good = true;
+                        for (size_t k = 0; k < call->second.size() && good; ++k) {
+                            BaItem it;
+                            it.id = call->second[k];
+                            it.orig = (int32_t)k;
+                            good = bounding_box(s, it.id, h.d[0], h.d[1], it.box);
+                            objs.push_back(it);
+                        }
+                        AABB box;
+                        if (good) return emit_best_axis(objs, parent_scope, scope_depth, in_boundary, need, &box);
+                    }
                 }
                 uint32_t idx = (uint32_t)out.size();
                 RtNode n = blank(h.right >= 0 ? RT_BVH2 : RT_BVH1);
@@ -536,6 +617,7 @@ int rt1w_hittable_aabox(rt1w_scene* s, const double p0[3], const double p1[3], i
     for (int id : sides) s->hittables[id].used = true;
     int bvh = bvh_new(*s, sides, 0.0, 1.0);
     if (bvh < 0) return bvh;
+    s->bvh_calls[bvh] = sides;
     s->hittables[bvh].used = true;
     HostHittable h; h.kind = H_AABOX; h.child = bvh; h.has_box = true;
     h.box.minimum = rt_v3(p0[0], p0[1], p0[2]); h.box.maximum = rt_v3(p1[0], p1[1], p1[2]);
@@ -605,7 +687,9 @@ int rt1w_hittable_bvh(rt1w_scene* s, const int* children, uint32_t n, double tim
         int rc = take_child(s, id);
         if (rc < 0) return rc;
     }
-    return bvh_new(*s, objs, time0, time1);
+    const int root = bvh_new(*s, objs, time0, time1);
+    if (root >= 0) s->bvh_calls[root] = objs;
+    return root;
 }
 
 /* ---- scene-level ---- */
@@ -812,7 +896,7 @@ int rt1w_scene_set_walk_order(rt1w_scene* s, uint32_t mode) {
 int rt1w_scene_set_bvh_build(rt1w_scene* s, uint32_t mode) {
     if (!s) { set_error("null scene"); return RT1W_ERR_INVALID; }
     if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }
-    if (mode > RT1W_BVH_SAH) { set_error("unknown BVH build"); return RT1W_ERR_INVALID; }
+    if (mode > RT1W_BVH_BEST_AXIS) { set_error("unknown BVH build"); return RT1W_ERR_INVALID; }
     const uint32_t before = s->bvh_build;
     s->bvh_build = mode;
     int rc = flatten_scene(s);

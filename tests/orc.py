@@ -37,6 +37,9 @@ for _L in (A, REF):
 for _L in (A, REF):
     _L.orc_scene_apply_topology.restype = C.c_int
     _L.orc_scene_apply_topology.argtypes = [_P, _P, C.c_uint64]
+    _L.orc_scene_apply_topology_mode.restype = C.c_int
+    _L.orc_scene_apply_topology_mode.argtypes = [_P, _P, C.c_uint64, C.c_int]
+    _L.orc_set_bvh_axis_rule.argtypes = [C.c_int]
 REF.orc_ref_chacha_block.argtypes = [_P, C.c_uint64, C.c_int, _P]
 REF.orc_ref_stdrng_construction.argtypes = [_P, _P]
 REF.orc_ref_words.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, _P]
@@ -74,7 +77,9 @@ class OracleScene:
 
     lib = A  # class default (subclasses that wrap a ready handle); instances made with refstream=True use REF
 
-    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False):
+    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False, best_axis=False):
+        """best_axis: BVHNode::new with the axis of bvh.rs:84 chosen by the cost of its median split instead of drawn (the oracle's own
+        statement of the product's opt-in RT1W_BVH_BEST_AXIS; oracle.cpp: BVHNode::best_axis)."""
         self.lib = REF if refstream else A
         if aspect_ratio is None:
             aspect_ratio = default_aspect(arm)
@@ -86,7 +91,11 @@ class OracleScene:
             eh, ew = self.earth.shape[:2]
             ptr = self.earth.ctypes.data_as(_P)
         d = (C.c_uint32 * 3)()
-        self._h = self.lib.orc_scene_build(arm, build_seed, aspect_ratio, ptr, ew, eh, C.byref(d))
+        self.lib.orc_set_bvh_axis_rule(1 if best_axis else 0)
+        try:
+            self._h = self.lib.orc_scene_build(arm, build_seed, aspect_ratio, ptr, ew, eh, C.byref(d))
+        finally:
+            self.lib.orc_set_bvh_axis_rule(0)
         if not self._h:
             raise RuntimeError("oracle scene build failed")
         self.defaults = (d[0], d[1], d[2])
@@ -118,11 +127,12 @@ class OracleScene:
         assert rc == 0
         return out, {"segments": seg.value, "paths": tw * th * checkpoints[-1]}
 
-    def apply_topology(self, topo):
+    def apply_topology(self, topo, merge_nested=True):
         """Rebuild every BVH of this oracle scene over its own leaves with the trees of `topo` (the product's opt-in SAH build,
-        Scene.bvh_topology()); afterwards render() runs the literal BVHNode::hit over those trees.  Returns self."""
+        Scene.bvh_topology(); merge_nested=False for the best-axis build, whose nested BVHNode::new calls stay BVHs of their own);
+        afterwards render() runs the literal BVHNode::hit over those trees.  Returns self."""
         t = np.ascontiguousarray(topo, dtype=np.int32)
-        rc = self.lib.orc_scene_apply_topology(self._h, t.ctypes.data_as(_P), t.size)
+        rc = self.lib.orc_scene_apply_topology_mode(self._h, t.ctypes.data_as(_P), t.size, 1 if merge_nested else 0)
         assert rc == 0, "the topology stream does not fit this scene"
         return self
 

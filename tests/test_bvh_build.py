@@ -155,8 +155,81 @@ def test_sah_build_with_near_far_order(rt):
 def test_sah_build_errors(rt):
     lib = rt._lib
     sc = rt.Scene.reference(5, build_seed=1)
-    assert lib.rt1w_scene_set_bvh_build(sc._h, 2) < 0 and b"unknown" in lib.rt1w_last_error()
+    assert lib.rt1w_scene_set_bvh_build(sc._h, 3) < 0 and b"unknown" in lib.rt1w_last_error()
     assert lib.rt1w_scene_set_bvh_build(None, 1) < 0
+
+
+# ---- RT1W_BVH_BEST_AXIS: BVHNode::new as written, the axis of bvh.rs:84 chosen instead of drawn ----------------------------------
+
+@pytest.mark.parametrize("arm", sorted(ARMS))
+def test_best_axis_trees_are_the_reference_rule_and_equal_the_oracles_own(rt, arm):
+    """The best-axis build keeps the reference's rule (bvh.rs:60-100: stable sort by box minimum, split at len/2, one- and two-object
+    shapes, nested BVHNode::new calls separate) and only picks the axis.  Checked three ways: (1) same leaves, children boxes inside
+    their parent's, the reference's shape; (2) the literal oracle rebuilt over the product's topology stream (merge_nested=False) and
+    (3) the literal oracle built NATIVELY with its own statement of the rule (oracle.cpp: BVHNode::best_axis) render the same bits, and
+    the CPU build of the core on the product's flattened scene reproduces them: equal segment counts, <= 1e-12 relative."""
+    W, H, spp = ARMS[arm]
+    aspect = 1.5 if arm == 0 else None
+    ref = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
+    ba = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build("best_axis")
+    assert _leaf_multiset(ref) == _leaf_multiset(ba)
+    assert len(_nodes(ref)[0]) == len(_nodes(ba)[0])        # a median split per node: as many nodes as the reference's own tree
+    u, f = _nodes(ba)
+    kinds = u[:, 0] & 0xFF
+    for i in np.nonzero(kinds == KIND_BVH2)[0]:
+        a, b = int(u[i, 22]), int(u[i, 14])
+        assert a == i + 1 and b == int(u[a, 1])
+        for c in (a, b):
+            if kinds[c] <= KIND_BVH1:
+                assert (f[c, 1:4] >= f[i, 1:4] - 2e-4).all() and (f[c, 4:7] <= f[i, 4:7] + 2e-4).all()
+    topo = ba.bvh_topology()
+    by_topology = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect).apply_topology(topo, merge_nested=False)
+    native = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect, best_axis=True)
+    a, sa = by_topology.render(W, H, spp)
+    n, sn = native.render(W, H, spp)
+    b, sb = orc.flat_render(ba, W, H, spp)
+    assert np.array_equal(a, n, equal_nan=True) and sa["segments"] == sn["segments"], arm
+    assert sa["segments"] == sb["segments"] and _close(a, b), arm
+    # static media-free arms: the frame does not depend on the tree; back to the reference build: the very same bytes
+    if arm in (1, 2, 3, 4, 5, 6):
+        r, sr = orc.flat_render(ref, W, H, spp)
+        assert np.array_equal(r, b, equal_nan=True)
+    assert ba.set_bvh_build(False).flat(0).tobytes() == ref.flat(0).tobytes()
+
+
+def test_best_axis_trees_of_random_graphs_against_the_literal_oracle(rt):
+    """The same on 24 random graphs: BVHs inside BVHs (kept separate), under wrappers, inside AABoxes, one- and two-object BVHs."""
+    for seed in range(24):
+        prod, oracle = random_scene_pair(3000 + seed)
+        leaves = _leaf_multiset(prod)
+        prod.set_bvh_build("best_axis")
+        assert _leaf_multiset(prod) == leaves, seed
+        oracle.apply_topology(prod.bvh_topology(), merge_nested=False)
+        W, H, spp = 28, 20, 4
+        a, sa = oracle.render(W, H, spp)
+        b, sb = orc.flat_render(prod, W, H, spp, variant=3)
+        assert sa["segments"] == sb["segments"] and _close(a, b), seed
+
+
+def test_best_axis_picks_the_cheapest_median_split(rt):
+    """Known answer: four unit spheres in a row along z (and a fifth far away on z) have one good median split -- by z.  The root's
+    children must separate low z from high z whatever the build seed draws."""
+    lib = rt._lib
+    for seed in (1, 2, 3, 7):
+        sc = rt.Scene(build_seed=seed)
+        m = sc.lambertian(sc.solid_color((0.5, 0.5, 0.5)))
+        ids = [sc.sphere((0.1 * ((k * 7) % 5), 0.05 * ((k * 3) % 5), z), 0.5, m) for k, z in enumerate((0.0, 30.0, 10.0, 40.0, 20.0))]
+        sc.set_world(sc.bvh_node(ids))
+        sc.set_camera((0, 0, -10), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+        sc.commit()
+        sc.set_bvh_build("best_axis")
+        u, f = _nodes(sc)
+        kinds = u[:, 0] & 0xFF
+        root = 0
+        assert kinds[root] == KIND_BVH2
+        a, b = int(u[root, 22]), int(u[root, 14])
+        # left = the len/2 = 2 lowest z (0, 10), right = the rest (20, 30, 40)
+        assert f[a, 6] < 15.0 and f[b, 3] > 15.0, (seed, f[a, 1:7], f[b, 1:7])
 
 
 @pytest.mark.gpu
@@ -185,3 +258,23 @@ def test_sah_build_on_the_gpu(rt, gpu_ctx_factory):
             assert np.array_equal(wf, want, equal_nan=True) and swf["segments"] == sw["segments"], arm
             f32, s32 = ctx.render(W, H, spp, f32=True)
             assert abs(np.nanmean(f32) - np.nanmean(want)) < 0.02 * np.nanmean(want)
+
+
+@pytest.mark.gpu
+def test_best_axis_build_on_the_gpu(rt, gpu_ctx_factory):
+    """The HIP kernels on the best-axis trees (pair walk on random_scene, sliced stack walk + slice-end reordering on final_scene, the
+    scene-specialised sweep on Cornell): bit-identical to the CPU build of the core on the same flattened scene, and within 1e-12 of
+    the literal oracle that built the same trees by its OWN statement of the rule (equal segment counts)."""
+    for arm, W, H, spp, aspect in ((0, 96, 64, 8, 1.5), (7, 64, 64, 8, None), (5, 64, 64, 16, None)):
+        sc = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build("best_axis")
+        lit, sl = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect, best_axis=True).render(W, H, spp)
+        want, sw = orc.flat_render(sc, W, H, spp)
+        ctx = gpu_ctx_factory(sc)
+        if arm == 5:
+            assert ctx.specialise()["active"]
+        got, sg = ctx.render(W, H, spp)
+        assert np.array_equal(got, want, equal_nan=True) and sg["segments"] == sw["segments"] == sl["segments"], arm
+        assert _close(lit, got), arm
+        if arm == 0:
+            assert sg["sorted"] & 128, "random_scene on the best-axis tree did not run the pair-walk kernel"
+        ctx.close()

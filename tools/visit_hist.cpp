@@ -15,12 +15,13 @@ struct cam_bg { RtCamera cam; RtV3 bg; uint32_t root, pad; };
 int main(int argc, char** argv) {
     int arm = atoi(argv[1]), W = atoi(argv[2]), H = atoi(argv[3]), spp = atoi(argv[4]);
     static const char* names[16] = {"bvh2", "bvh1", "sphere", "msphere", "xy", "xz", "yz", "translate", "rotate_y", "flip", "medium", "?", "?", "?", "?", "?"};
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 6; ++mode) {
         std::vector<uint8_t> earth(1024 * 512 * 3, 128);
         rt1w_scene* s = nullptr; uint32_t def[3];
         if (rt1w_scene_build_reference(arm, 1, (double)W / H, earth.data(), 1024, 512, &s, def)) { printf("fail\n"); return 1; }
-        if (mode & 1) rt1w_scene_set_bvh_build(s, RT1W_BVH_SAH);
-        if (mode & 2) rt1w_scene_set_walk_order(s, RT1W_WALK_NEAR_FAR);
+        if (mode >= 4) rt1w_scene_set_bvh_build(s, RT1W_BVH_BEST_AXIS); else if (mode & 1) rt1w_scene_set_bvh_build(s, RT1W_BVH_SAH);
+        if (mode == 5) rt1w_scene_set_walk_order(s, RT1W_WALK_NEAR_FAR);
+        if (mode < 4 && (mode & 2)) rt1w_scene_set_walk_order(s, RT1W_WALK_NEAR_FAR);
         std::vector<std::vector<uint8_t>> a(7);
         for (int i = 0; i < 7; i++) { int64_t n = rt1w_scene_copy_flat(s, i, nullptr, 0); a[i].resize(n > 0 ? n + 96 : 16); rt1w_scene_copy_flat(s, i, a[i].data(), a[i].size()); }
         rt1w_scene_info inf; rt1w_scene_get_info(s, &inf);
@@ -37,12 +38,12 @@ int main(int argc, char** argv) {
             RtPath p; rt_path_begin(sc, f, x, y, k, p);
             while (p.alive) {
                 segs += p.depth_left != 0u;
-                RtTrace tr = (mode & 2) ? rt_path_trace<RtCfgV4>(sc, ns, p, stk) : rt_path_trace<RtCfgV3>(sc, ns, p, stk);
+                RtTrace tr = ((mode & 2) || mode == 5) ? rt_path_trace<RtCfgV4>(sc, ns, p, stk) : rt_path_trace<RtCfgV3>(sc, ns, p, stk);
                 rt_path_shade<RtCfgV3>(sc, p, tr);
             }
         }
         unsigned long long tot = 0; for (int i = 0; i < 16; i++) tot += g_hist[i];
-        printf("arm %d %-9s%-9s nodes %5u: %.2f visits/segment:", arm, (mode & 1) ? "SAH" : "reference", (mode & 2) ? "+near-far" : "", inf.n_nodes, (double)tot / segs);
+        printf("arm %d %-9s%-9s nodes %5u: %.2f visits/segment:", arm, mode >= 4 ? "best-axis" : (mode & 1) ? "SAH" : "reference", ((mode & 2) || mode == 5) ? "+near-far" : "", inf.n_nodes, (double)tot / segs);
         for (int i = 0; i < 11; i++) if (g_hist[i]) printf(" %s %.2f", names[i], (double)g_hist[i] / segs);
         printf("\n");
         rt1w_scene_destroy(s);
