@@ -43,7 +43,8 @@ extern "C" int rt1w_internal_f32_create(const void* nodes, uint32_t n_nodes, con
                                         uint32_t n_materials, const void* textures, uint32_t n_textures, const void* perlin, uint32_t n_perlin,
                                         const void* view64, void** out);
 extern "C" void rt1w_internal_f32_destroy(void* h);
-extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted);
+extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted); /* sorted 2: the pair-walk kernel of sphere scenes */
+extern "C" int rt1w_internal_f32_pw(void* h, unsigned stack_cap); /* 1: the scene has f32 pair-walk records and fits `stack_cap` entries */
 extern "C" unsigned rt1w_internal_f32_view(void* h, void* out, unsigned cap); /* bytes of the f32 RtSceneView (kernel argument) */
 extern "C" int rt1w_internal_f32_launch(void* h, int variant, int sorted, const void* frame, double* partial, unsigned long long* counters, int grid,
                                         hipStream_t stream);
@@ -70,12 +71,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss(
     rt_render_ss_body<Cfg, CAP, PARTS>(sc, f, partial, counters);
 }
 
-/* the same for sphere scenes: the pair walk in slices + the reordering of the finished paths (RT_PW_SS_STACK entries per lane instead of
- * RT_PW_STACK: what leaves room for the exchange buffer next to the pair walk's stacks and queues at three workgroups per CU) */
-#define RT_PW_SS_STACK 12
-#ifndef RT_PW_SS_PARTS
-#define RT_PW_SS_PARTS 3 /* rounds of the exchange */
-#endif
+/* the same for sphere scenes: the pair walk in slices + the reordering of the finished paths (RT_PW_SS_STACK, rt_kernel_plain.h) */
 #ifndef RT_SS_CAP
 #define RT_SS_CAP RT_STACK_CAP /* stack entries per lane of the stack-walk kernels that reorder (experiments: 16 for four workgroups per CU) */
 #endif
@@ -206,7 +202,7 @@ struct rt1w_context {
     int pw_grid = 0, pw_ss_grid = 0;
     /* host copies of the flat arrays the two opt-in modes convert on first use (a scene may be destroyed before its contexts) */
     std::vector<RtNode> h_nodes, h_lights; std::vector<RtMaterial> h_materials; std::vector<RtTexture> h_textures; std::vector<RtPerlin> h_perlin;
-    int f32_grid[RT_N_VARIANTS][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int f32_grid[RT_N_VARIANTS][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; /* [variant][plain, reordering, pair walk] */
     /* scene-specialised kernel (jit.cpp): generated source (empty: scene not eligible), loaded module */
     std::string jit_src, jit_key;
     hipModule_t jit_mod = nullptr;
@@ -380,11 +376,13 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
         }
         const bool sorted = !(p->flags & RT1W_UNSORTED) && (v < 2 || !getenv("RT1W_NO_SLICE_SORT")); /* v >= 2: the slice-end reordering of the stack walks */
         L.ss = sorted && v >= 2;
-        int& g = c->f32_grid[v][sorted ? 1 : 0];
+        /* sphere scenes: the pair walk (rt_walk_pair.h) in this precision too -- in the kernel that reorders the finished paths */
+        L.pw = L.ss && v == 5 && !(p->flags & RT1W_CLASSIC_WALK) && !getenv("RT1W_CLASSIC_WALK") && rt1w_internal_f32_pw(c->f32_scene, (unsigned)RT_PW_SS_STACK) == 1;
+        int& g = c->f32_grid[v][L.pw ? 2 : (sorted ? 1 : 0)];
         if (!g) {
             hipDeviceProp_t prop;
             if (!hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
-            g = prop.multiProcessorCount * rt1w_internal_f32_blocks_per_cu(v, sorted ? 1 : 0);
+            g = prop.multiProcessorCount * rt1w_internal_f32_blocks_per_cu(v, L.pw ? 2 : (sorted ? 1 : 0));
         }
         L.f32 = true; L.jit = false; L.sorted = sorted; L.cached = false; L.variant = v; L.grid = g; L.block = sorted ? RT_SORT_BLOCK : RT_BLOCK;
         return RT1W_OK;
@@ -453,7 +451,7 @@ int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const
         void* args[] = {view32, &frame, &partial, &counters};
         if (!hip_ok(hipModuleLaunchKernel(c->jit32_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised f32 kernel launch")) return RT1W_ERR_DEVICE;
     } else if (L.f32) {
-        if (!c->f32_scene || rt1w_internal_f32_launch(c->f32_scene, L.variant, L.sorted ? 1 : 0, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
+        if (!c->f32_scene || rt1w_internal_f32_launch(c->f32_scene, L.variant, L.pw ? 2 : (L.sorted ? 1 : 0), &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
             rt1w::set_error("single-precision kernel launch failed"); return RT1W_ERR_DEVICE;
         }
     } else if (L.ref) {

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <new>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -27,6 +28,7 @@
 #undef RT1W_CORE_H
 #undef RT_KERNEL_SORTED_H
 #undef RT_KERNEL_PLAIN_H
+#undef RT1W_WALK_PAIR_H
 #define RT_F32 1
 #define double float
 
@@ -53,6 +55,11 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_k
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, RT_F32_WAVES(Cfg)) void rt_render_kernel_ss_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
     rt_render_ss_body<Cfg, RT_STACK_CAP, 3>(sc, f, partial, counters);
+}
+/* sphere scenes: the pair walk (rt_walk_pair.h: inner boxes and group boxes are both this build's f32 boxes, widened like every BVH box of
+ * this mode) in slices + the reordering of the finished paths */
+__global__ __launch_bounds__(RT_BLOCK, 3) void rt_render_kernel_pw_ss_f32(RtSceneView sc, RtPwView pw, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {
+    rt_render_ss_body<RtCfgV5, RT_PW_SS_STACK, RT_PW_SS_PARTS, true>(sc, f, partial, counters, &pw);
 }
 typedef void (*kernel_t)(RtSceneView, RtFrame, rt_f64*, unsigned long long*);
 static kernel_t const g_plain[RT_N_VARIANTS] = {rt_render_kernel_f32<RtCfgV0>, rt_render_kernel_f32<RtCfgV1>, rt_render_kernel_f32<RtCfgV2>, rt_render_kernel_f32<RtCfgV3>,
@@ -88,7 +95,11 @@ rtf32::RtNode conv_node(const ::RtNode& n) {
 
 struct F32Scene {
     void* nodes = nullptr; void* lights = nullptr; void* materials = nullptr; void* textures = nullptr; void* perlin = nullptr;
+    void* pw_inner = nullptr; void* pw_groups = nullptr;
     rtf32::RtSceneView view;
+    rtf32::RtPwView pw;
+    bool pw_ok = false;
+    uint32_t pw_stack = 0; /* pushed right children a walk can hold at once: the depth of the inner-record tree */
 };
 
 template <class T>
@@ -106,7 +117,7 @@ rtf32::RtV3 v3f(const ::RtV3& v) { rtf32::RtV3 o; o.x = (float)v.x; o.y = (float
 extern "C" void rt1w_internal_f32_destroy(void* h) {
     F32Scene* s = static_cast<F32Scene*>(h);
     if (!s) return;
-    void* bufs[] = {s->nodes, s->lights, s->materials, s->textures, s->perlin};
+    void* bufs[] = {s->nodes, s->lights, s->materials, s->textures, s->perlin, s->pw_inner, s->pw_groups};
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete s;
 }
@@ -159,8 +170,32 @@ extern "C" int rt1w_internal_f32_create(const void* nodes_, uint32_t n_nodes, co
     v.camera.vertical = v3f(c.vertical); v.camera.u = v3f(c.u); v.camera.v = v3f(c.v); v.camera.w = v3f(c.w);
     v.camera.lens_radius = (float)c.lens_radius; v.camera.time0 = (float)c.time0; v.camera.time1 = (float)c.time1;
     v.background = v3f(v64.background);
+    /* pair-walk records of a sphere scene, from THIS build's node array (boxes already widened by conv_node) */
+    {
+        std::vector<rtf32::RtNode> only(fn.begin(), fn.begin() + n_nodes);
+        std::vector<rtf32::RtPwInner> pin;
+        std::vector<rtf32::RtPwGroup> pgr;
+        std::string why;
+        memset(&s->pw, 0, sizeof s->pw);
+        if (n_nodes > 0 && rtf32::rt_pw_build(only, v64.root, pin, pgr, s->pw, why) && upload_vec(&s->pw_inner, pin) && upload_vec(&s->pw_groups, pgr)) {
+            s->pw.inner = (const rtf32::RtPwInner*)s->pw_inner; s->pw.groups = (const rtf32::RtPwGroup*)s->pw_groups;
+            /* deepest chain of inner records: a walk pushes at most one right child per level */
+            struct D { static uint32_t of(const std::vector<rtf32::RtPwInner>& v, uint32_t i) {
+                if (i & RT_PW_LEAF) return 0u;
+                const uint32_t a = of(v, v[i].l), b = of(v, v[i].r);
+                return 1u + (a > b ? a : b);
+            } };
+            s->pw_stack = (s->pw.root & RT_PW_LEAF) ? 0u : D::of(pin, s->pw.root);
+            s->pw_ok = true;
+        }
+    }
     *out = s;
     return 0;
+}
+
+extern "C" int rt1w_internal_f32_pw(void* h, unsigned stack_cap) {
+    F32Scene* s = static_cast<F32Scene*>(h);
+    return (s && s->pw_ok && s->pw_stack <= stack_cap) ? 1 : 0;
 }
 
 extern "C" unsigned rt1w_internal_f32_view(void* h, void* out, unsigned cap) {
@@ -173,6 +208,10 @@ extern "C" unsigned rt1w_internal_f32_view(void* h, void* out, unsigned cap) {
 extern "C" int rt1w_internal_f32_blocks_per_cu(int variant, int sorted) {
     int per_cu = 0;
     if (variant < 0 || variant >= RT_N_VARIANTS) return 0;
+    if (sorted == 2) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtf32::rt_render_kernel_pw_ss_f32, RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        return per_cu;
+    }
     rtf32::kernel_t k = sorted ? rtf32::g_sorted[variant] : rtf32::g_plain[variant];
     if (!k) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, sorted ? RT_SORT_BLOCK : RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -189,6 +228,11 @@ extern "C" int rt1w_internal_f32_launch(void* h, int variant, int sorted, const 
     rtf32::RtFrame f;
     static_assert(sizeof(rtf32::RtFrame) == sizeof(::RtFrame), "RtFrame has no floating-point fields");
     memcpy(&f, frame, sizeof f);
+    if (sorted == 2) { /* the pair-walk kernel of sphere scenes (variant 5 only; the caller asked rt1w_internal_f32_pw first) */
+        if (variant != 5 || !s->pw_ok) return -1;
+        hipLaunchKernelGGL(rtf32::rt_render_kernel_pw_ss_f32, dim3(grid), dim3(RT_BLOCK), 0, stream, s->view, s->pw, f, partial, counters);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(sorted ? RT_SORT_BLOCK : RT_BLOCK), 0, stream, s->view, f, partial, counters);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -4,12 +4,21 @@
 #define RT_KERNEL_PLAIN_H
 
 #include "rt_kernel_sorted.h"
-#if !defined(RT_RNG_REFSTREAM) && !defined(RT_F32)
+#if !defined(RT_RNG_REFSTREAM)
 #include "rt_walk_pair.h"
 #define RT_HAVE_PW 1
 #else
-#undef RT_HAVE_PW /* the reference-stream and f32 builds of this header keep the one-entry-per-step walk */
+#undef RT_HAVE_PW /* the reference-stream build of this header keeps the one-entry-per-step walk */
 struct RtPwView { int unused; };
+#endif
+/* the pair walk in the kernel that also reorders the finished paths: RT_PW_SS_STACK entries per lane instead of RT_PW_STACK (what leaves
+ * room for the exchange buffer next to the pair walk's stacks and queues at three workgroups per CU), the exchange in RT_PW_SS_PARTS rounds */
+#define RT_PW_SS_STACK 12
+#ifndef RT_PW_SS_PARTS
+#define RT_PW_SS_PARTS 3
+#endif
+#ifndef RT_CAM_AT_USE
+#define RT_CAM_AT_USE 1 /* rt_render_ss_body reads the camera block by scalar loads where a path begins instead of holding it across the loop */
 #endif
 #ifndef RT_PW_BOX_STEPS
 #define RT_PW_BOX_STEPS 6 /* inner records a lane visits per vote */
@@ -386,13 +395,22 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
  * 3: 337, 2: 346 */
 #define RT_SS_BOX_STEPS(Cfg) (Cfg::media ? (Cfg::ordered ? 2 : 3) : 0)
 #endif
-/* The other waves' counters are read while they write them -- a hint, not a synchronisation: a stale value only delays the stop by a
- * round, and the loop ends by itself when the wave's own walks are over.  The compiler-level fence (no instruction) keeps the four
- * loads from being held in registers across rounds; they still go out as one LDS load (declaring the counters volatile instead: four
- * separate loads in program order, -3 %).  By the cycle stamps the waves still spend 18 % of their time at the sort's barrier
+/* The workgroup's counter is read while other waves add to it -- a hint, not a synchronisation: a stale value only delays the stop by a
+ * round, and the loop ends by itself when the wave's own walks are over.  By the cycle stamps the waves still spend 18 % of their time at the sort's barrier
  * (final_scene; 10 % on random_scene): measured and NOT the cure -- ending the slice as soon as any wave has no walk left (302 against
  * 304 Mpaths/s), or only after every wave has passed 2 / 4 / 8 checks in it (312-318 against 316-318); profiles/r03_slice_sort.txt. */
-#define RT_SS_FENCE_HERE() asm volatile("" ::: "memory")
+/* Round 4: the counter is ONE word per slice that every wave adds its newly finished walks to (a relaxed workgroup-scope atomic add by
+ * the wave's first walking lane, `ds_add_u32`) and reads back with a relaxed atomic load: the same hint with defined behaviour in the
+ * HIP memory model (round 3 had four plain words written by one wave and read by the others with only a compiler fence between). */
+#define RT_SS_PUBLISH(done_now)                                                                                                   \
+    do {                                                                                                                          \
+        const uint32_t d_ = (done_now);                                                                                           \
+        if (d_ != ss_pub) {                                                                                                       \
+            if (lane == lead_) __hip_atomic_fetch_add(&ss_done[parity], d_ - ss_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            ss_pub = d_;                                                                                                          \
+        }                                                                                                                         \
+    } while (0)
+#define RT_SS_TOTAL() __hip_atomic_load(&ss_done[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #ifndef RT_SS_WG_SLICE
 #define RT_SS_WG_SLICE 1 /* the slice ends for the whole workgroup at once: every wave publishes how many of its walks have ended and all stop
                             when the workgroup's total reaches 4 x RT_SS_IDLE -- the waves then reach the sort's barrier within a round of each other.
@@ -420,9 +438,9 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
 #endif
     __shared__ unsigned long long xch[RT_SS_PER * RT_BLOCK];
     __shared__ uint32_t cnt[4][RT_SS_KEYS + 1u]; /* [wave][key]; last column: lanes of the wave that are not walking */
-    __shared__ uint32_t ss_done[2][4];           /* [slice parity][wave]: walks of the wave that have ended in this slice */
-    uint32_t parity = 0u;
-    if (threadIdx.x < 8u) ss_done[threadIdx.x >> 2][threadIdx.x & 3u] = 0u;
+    __shared__ uint32_t ss_done[2];              /* [slice parity]: walks of the workgroup that have ended in this slice */
+    uint32_t parity = 0u, ss_pub = 0u;           /* ss_pub: what this wave has added to ss_done[parity] so far (wave-uniform) */
+    if (threadIdx.x < 2u) ss_done[threadIdx.x] = 0u;
     __syncthreads();
     LdsStack stk;
     stk.base = stack_mem + threadIdx.x;
@@ -483,6 +501,9 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
                 }
             }
             if (!have) retired = true;
+#if !RT_CAM_AT_USE
+            else rt_path_begin(sc, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
+#else
             else {
                 /* the camera block is read where it is used, by scalar loads from the kernel-argument segment: held across the loop its
                  * 24 doubles cost 48 SGPRs the walk needs (they were spilled to VGPR lanes and to scratch) */
@@ -496,6 +517,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
                 cam.lens_radius = kc[21]; cam.time0 = kc[22]; cam.time1 = kc[23];
                 rt_path_begin_cam(cam, f, f.x0 + px, rt_frame_row(f, py), f.sample_offset + s, path);
             }
+#endif
         }
         RT_STAMP(1);
         RtTrace tr;
@@ -530,10 +552,8 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
                     {
                         const uint32_t n_ = (uint32_t)__popcll(__ballot(more));
                         if constexpr (RT_SS_WG_SLICE) {
-                            if (lane == lead_) ss_done[parity][wave] = lanes_here - n_;
-                            RT_SS_FENCE_HERE();
-                            const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];
-                            on_ = n_ != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);
+                            RT_SS_PUBLISH(lanes_here - n_);
+                            on_ = n_ != 0u && RT_SS_TOTAL() < 4u * (uint32_t)RT_SS_IDLE(Cfg);
                         } else on_ = n_ > stop_at;
                     }
                     if (!on_) break;
@@ -606,10 +626,8 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             /* wave-uniform: does the slice go on?  (n = lanes of this wave still walking; a macro, see RT_SLICE_BOX_STEPS_HERE) */
 #define RT_SS_GOES_ON(n, out)                                                                                         \
     if constexpr (RT_SS_WG_SLICE) {                                                                                   \
-        if (lane == lead_) ss_done[parity][wave] = lanes_here - (n);                                                  \
-        RT_SS_FENCE_HERE();                                                                                           \
-        const uint32_t total_ = ss_done[parity][0] + ss_done[parity][1] + ss_done[parity][2] + ss_done[parity][3];    \
-        out = (n) != 0u && total_ < 4u * (uint32_t)RT_SS_IDLE(Cfg);                                                        \
+        RT_SS_PUBLISH(lanes_here - (n));                                                                              \
+        out = (n) != 0u && RT_SS_TOTAL() < 4u * (uint32_t)RT_SS_IDLE(Cfg);                                            \
     } else out = (n) > stop_at;
 #define RT_SS_BOX_STEPS_HERE()                                                                                      \
     if constexpr (RT_SS_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) { \
@@ -667,7 +685,10 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         RT_STAMP(8);
         __syncthreads();
         RT_STAMP(9);
-        if constexpr (RT_SS_WG_SLICE) { if (lane == 0u) ss_done[parity ^ 1u][wave] = 0u; parity ^= 1u; } /* the next slice's counters: nobody reads them before the barriers below */
+        if constexpr (RT_SS_WG_SLICE) { /* the next slice's counter: nobody touches it before the barriers below */
+            if (threadIdx.x == 0u) __hip_atomic_store(&ss_done[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            parity ^= 1u; ss_pub = 0u;
+        }
         uint32_t dest = my_rank, idle_total = 0;
 #pragma unroll
         for (uint32_t c = 0; c < RT_SS_KEYS; ++c) {

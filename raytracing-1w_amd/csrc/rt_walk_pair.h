@@ -37,7 +37,7 @@ struct RtPwPrim {
     double radius;
     uint32_t id;         /* index of the primitive's RtNode: what the walk reports */
     uint32_t moving;
-}; /* 64 bytes */
+}; /* 64 bytes (36 in the f32 build, where `double` is `float`: context_f32.hip builds its own records from its own node array) */
 struct RtPwGroup {
     double box[6];       /* the group's own box: BVHNode.aabb of the One / Two node, the reference's bits */
     uint32_t n, pad[3];
@@ -230,7 +230,7 @@ inline bool rt_pw_build(const std::vector<RtNode>& N, uint32_t root, std::vector
         if (!b.is_prim(i)) { why = "a node that is neither a BVH node nor a sphere"; return false; }
         if (k == RT_MSPHERE) {
             if (!seen_ms) { t0 = N[i].e[0]; t1 = N[i].e[1]; seen_ms = true; }
-            else if (std::memcmp(&t0, &N[i].e[0], 8) != 0 || std::memcmp(&t1, &N[i].e[1], 8) != 0) { why = "moving spheres with different shutter intervals"; return false; }
+            else if (std::memcmp(&t0, &N[i].e[0], sizeof t0) != 0 || std::memcmp(&t1, &N[i].e[1], sizeof t1) != 0) { why = "moving spheres with different shutter intervals"; return false; }
         }
     }
     view.ms_time0 = t0; view.ms_time1 = t1;

@@ -5,7 +5,8 @@
     (final_scene, an earlier revision) read from /root/reference -- the only outputs of the reference's own runs
     that match a scene arm of master (one_weekend.png is the book-1 scene: gradient sky, no checker, no motion blur);
 (2) golden framebuffers of the literal CPU oracle (oracle/oracle.cpp) for small
-    configurations of every scene arm, incl. BASELINE config C1 (Cornell 200x200x64).
+    configurations of every scene arm, incl. BASELINE config C1 (Cornell 200x200x64);
+(3) block means of the same oracle built with `type Float = f32` (oracle/oracle_f32.cpp) -- `make_golden.py f32` makes only these.
 The reference (Rust) cannot be run here, so (2) are oracle outputs, not reference
 outputs; (1) is the reference's.
 """
@@ -97,7 +98,31 @@ CASES = {  # name: (arm, W, H, spp, depth)
     "cornell_depth3_48x48x8": (5, 48, 48, 8, 3),
 }
 
+F32_CASES = {  # name: (arm, W, H, spp, block, aspect)
+    "cornell_600x600x256": (5, 600, 600, 256, 100, None),
+    "random_scene_300x200x64": (0, 300, 200, 64, 50, 1.5),
+    "final_scene_200x200x64": (7, 200, 200, 64, 50, None),
+}
+
+def f32_frames():
+    """(3) Block means of the literal oracle built with the reference's precision switch thrown, `type Float = f32` (main.rs:1;
+    oracle/oracle_f32.cpp): the expected side of the product's RT1W_PRECISION_F32 mode.  Linear means per block and channel, NaN
+    pixels (zeroed by into_sampled, color.rs:16-18, before they get here) counted through their zeros."""
+    out = {}
+    for name, (arm, W, H, spp, blk, aspect) in F32_CASES.items():
+        img, st = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect, f32=True).render(W, H, spp)
+        bm = img.reshape(H // blk, blk, W // blk, blk, 3).mean(axis=(1, 3))
+        out[name] = {"arm": arm, "W": W, "H": H, "spp": spp, "block": blk, "aspect": aspect, "segments": st["segments"],
+                     "mean": float(img.mean()), "channel_means": img.mean(axis=(0, 1)).tolist(),
+                     "zero_channels": int((img == 0.0).sum()), "block_means_bottom_up": bm.tolist()}
+        print(name, st["segments"], out[name]["mean"])
+    with open(os.path.join(HERE, 'oracle_f32_blocks.json'), 'w') as f:
+        json.dump({"build_seed": 1, "global_seed": 0, "source": "oracle/oracle_f32.cpp (liborc_f32.so)", "cases": out}, f, indent=1)
+
 def main():
+    if sys.argv[1:] == ["f32"]:
+        return f32_frames()
+    f32_frames()
     with open(os.path.join(HERE, 'cornell_png_blocks.json'), 'w') as f:
         json.dump(png_blocks(), f, indent=1)
     with open(os.path.join(HERE, 'final_scene_png_blocks.json'), 'w') as f:

@@ -34,7 +34,15 @@ for _L in (A, REF):
     _L.orc_render_checkpoints.argtypes = [_P] + [C.c_uint32] * 10 + [C.c_int, C.c_int, _P, C.c_uint32, _P, C.POINTER(C.c_uint64)]
     _L.orc_quantize.argtypes = [_P, C.c_uint64, _P]
     _L.orc_is_refstream.restype = C.c_int
-for _L in (A, REF):
+# the same restatement with `type Float = f32` (main.rs:1; oracle/oracle_f32.cpp): `double` parameters are `float` in this library
+F32 = C.CDLL(os.path.join(ORACLE_DIR, "liborc_f32.so"))
+F32.orc_scene_build.restype = _P
+F32.orc_scene_build.argtypes = [C.c_int, C.c_uint64, C.c_float, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 3)]
+F32.orc_scene_free.argtypes = [_P]
+F32.orc_render.restype = C.c_int
+F32.orc_render.argtypes = [_P] + [C.c_uint32] * 10 + [C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]
+F32.orc_quantize.argtypes = [_P, C.c_uint64, _P]
+for _L in (A, REF, F32):
     _L.orc_scene_apply_topology.restype = C.c_int
     _L.orc_scene_apply_topology.argtypes = [_P, _P, C.c_uint64]
     _L.orc_scene_apply_topology_mode.restype = C.c_int
@@ -77,10 +85,11 @@ class OracleScene:
 
     lib = A  # class default (subclasses that wrap a ready handle); instances made with refstream=True use REF
 
-    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False, best_axis=False):
+    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False, best_axis=False, f32=False):
         """best_axis: BVHNode::new with the axis of bvh.rs:84 chosen by the cost of its median split instead of drawn (the oracle's own
         statement of the product's opt-in RT1W_BVH_BEST_AXIS; oracle.cpp: BVHNode::best_axis)."""
-        self.lib = REF if refstream else A
+        self.lib = REF if refstream else (F32 if f32 else A)
+        self.f32 = bool(f32)  # the build with type Float = f32: frames come back as float32 and are widened here
         if aspect_ratio is None:
             aspect_ratio = default_aspect(arm)
         self.earth = None
@@ -107,13 +116,13 @@ class OracleScene:
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, out_sum=False, threads=None):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        out = np.empty((th, tw, 3), dtype=np.float64)
+        out = np.empty((th, tw, 3), dtype=np.float32 if getattr(self, "f32", False) else np.float64)
         seg = C.c_uint64()
         threads = threads or min(16, os.cpu_count() or 1)
         rc = self.lib.orc_render(self._h, width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed,
                                  1 if out_sum else 0, threads, out.ctypes.data_as(_P), C.byref(seg))
         assert rc == 0
-        return out, {"segments": seg.value, "paths": tw * th * spp}
+        return out.astype(np.float64), {"segments": seg.value, "paths": tw * th * spp}
 
     def render_checkpoints(self, width, height, checkpoints, max_depth=50, tile=None, threads=None):
         """One pass over max(checkpoints) samples; returns the means after each checkpoint: [n_cp][th][tw][3]."""
@@ -138,7 +147,7 @@ class OracleScene:
 
     def quantize(self, means):
         """The oracle's own quantiser (color.rs:56-65), not the product's."""
-        m = np.ascontiguousarray(means, dtype=np.float64)
+        m = np.ascontiguousarray(means, dtype=np.float32 if getattr(self, "f32", False) else np.float64)
         q = np.empty(m.shape, dtype=np.uint8)
         self.lib.orc_quantize(m.ctypes.data_as(_P), m.size, q.ctypes.data_as(_P))
         return q

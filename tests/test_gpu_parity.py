@@ -26,6 +26,16 @@ def close(a, b):
     return bool((both_nan | (np.abs(a - b) <= RTOL * np.abs(a)) | (a == b)).all())
 
 
+def literal_crop_check(arm, aspect, W, H, spp, tile, gpu_crop, flat_segments=None):
+    """A crop of a FULL-SIZE job against oracle A (oracle/oracle.cpp, the literal recursive restatement) rendering the same pixels of
+    the same W x H x spp job: <= 1e-12 relative (the chunked sum and the recursion associate differently), and the oracle's segment
+    count on the crop's paths equals the CPU core build's on the same crop (which the GPU frame equals bit for bit)."""
+    lit, sl = orc.OracleScene(arm, build_seed=1, aspect_ratio=aspect).render(W, H, spp, tile=tile)
+    assert close(lit, gpu_crop), (arm, tile)
+    if flat_segments is not None:
+        assert sl["segments"] == flat_segments, (arm, tile, sl["segments"], flat_segments)
+
+
 SMALL = {0: (96, 64, 8), 1: (64, 36, 8), 2: (64, 36, 8), 3: (64, 36, 8), 4: (64, 36, 16), 5: (64, 64, 16), 6: (64, 64, 16),
          7: (64, 64, 16)}
 
@@ -230,9 +240,10 @@ def test_c3_cornell_600x600_1000spp_properties(rt, gpu_ctx_factory):
     assert st["paths"] == 360_000_000 and 4.5 < st["segments"] / st["paths"] < 5.6
     # (a) crops of the full-size job against the CPU core build (same W,H,spp) -- bit exact
     for tile in ((0, 0, 8, 8), (296, 300, 8, 8), (592, 592, 8, 8)):
-        b, _ = orc.flat_render(sc, W, H, 1000, tile=tile, chunk=125)
+        b, sb = orc.flat_render(sc, W, H, 1000, tile=tile, chunk=125)
         x0, y0, w, h = tile
         assert np.array_equal(full[y0:y0 + h, x0:x0 + w], b)
+        literal_crop_check(5, None, W, H, 1000, tile, full[y0:y0 + h, x0:x0 + w], sb["segments"])
     # (b) tile renders equal the same region of the full render (image tiling across GPUs)
     strip, _ = ctx.render(W, H, 1000, tile=(0, 160, 600, 16), chunk=125)
     assert np.array_equal(strip, full[160:176])
@@ -275,9 +286,10 @@ def test_c2_random_scene_1200x800_500spp_crops(rt, gpu_ctx_factory):
     full, st = ctx.render(W, H, spp)
     assert st["paths"] == W * H * spp and np.isfinite(full).all()
     for tile in ((600, 400, 8, 8), (100, 60, 8, 4)):
-        b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=st["chunk"])
+        b, sb = orc.flat_render(sc, W, H, spp, tile=tile, chunk=st["chunk"])
         x0, y0, w, h = tile
         assert np.array_equal(full[y0:y0 + h, x0:x0 + w], b)
+        literal_crop_check(0, 1.5, W, H, spp, tile, full[y0:y0 + h, x0:x0 + w], sb["segments"])
     # sky: top-left pixel sees only background (0.7,0.8,1.0) -- or geometry; mean stays in gamut
     assert 0.0 < full.mean() < 1.0
 
@@ -290,6 +302,7 @@ def test_c4_final_scene_800x800_tile_at_10000spp(rt, gpu_ctx_factory):
     g, sg = ctx.render(800, 800, 10000, tile=tile)
     b, sb = orc.flat_render(sc, 800, 800, 10000, tile=tile, chunk=sg["chunk"])
     assert sg["segments"] == sb["segments"] and np.array_equal(g, b, equal_nan=True)
+    literal_crop_check(7, None, 800, 800, 10000, (392, 300, 8, 8), g[:8, :8])   # an 8x8 corner of the tile at the full 10 000 spp
 
 
 def test_c5_4k_cornell_tiles(rt, gpu_ctx_factory):
@@ -303,8 +316,9 @@ def test_c5_4k_cornell_tiles(rt, gpu_ctx_factory):
     y0, rows = sh.row_strips(H, 8, 3)[10]
     strip, st = ctx.render(W, H, 200, tile=(0, y0, W, rows))
     crop = (1900, y0 + 4, 8, 4)
-    b, _ = orc.flat_render(sc, W, H, 200, tile=crop, chunk=st["chunk"])
+    b, sb = orc.flat_render(sc, W, H, 200, tile=crop, chunk=st["chunk"])
     assert np.array_equal(strip[4:8, 1900:1908], b)
+    literal_crop_check(5, 16.0 / 9.0, W, H, 200, crop, strip[4:8, 1900:1908], sb["segments"])
 
 
 def test_two_contexts_render_concurrently_from_two_threads(rt, gpu_ctx_factory):
@@ -564,9 +578,10 @@ def test_c5_full_size_3840x2160_10000spp(rt, gpu_ctx_factory):
     assert np.isfinite(full).all() and 3.0 < st["segments"] / st["paths"] < 3.6
     chunk = rt.default_chunk(W, H, spp)
     for tile in ((1916, 1080, 4, 2), (8, 8, 2, 2)):
-        b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=chunk)
+        b, sb = orc.flat_render(sc, W, H, spp, tile=tile, chunk=chunk)
         x0, y0, w, h = tile
         assert np.array_equal(full[y0:y0 + h, x0:x0 + w], b)
+        literal_crop_check(5, 16.0 / 9.0, W, H, spp, tile, full[y0:y0 + h, x0:x0 + w], sb["segments"])
     one, _ = ctx.render(W, H, spp, tile=(0, 1072, W, 16), chunk=chunk)
     assert np.array_equal(one, full[1072:1088])
     # the ONE-SHOT entry on the same job: 20 chunks x 8.3 M pixels x 24 B = 4 GB of chunk partial sums in one launch
@@ -590,8 +605,9 @@ def test_c4_full_size_800x800_10000spp(rt, gpu_ctx_factory):
     final_png_block_check(full, 0.11, 0.02)
     final_png_disc_check(full, 0.08, "C4 full size: ")     # the literal objects (earth, moving sphere, blue ball): tighter than the blocks
     tile = (392, 300, 4, 2)
-    b, _ = orc.flat_render(sc, W, H, spp, tile=tile, chunk=rt.default_chunk(W, H, spp))
+    b, sb = orc.flat_render(sc, W, H, spp, tile=tile, chunk=rt.default_chunk(W, H, spp))
     assert np.array_equal(full[300:302, 392:396], b, equal_nan=True)
+    literal_crop_check(7, None, W, H, spp, tile, full[300:302, 392:396], sb["segments"])
     print(f"C4 full size: {st['total_ms'] / 1e3:.1f} s, {st['paths'] / st['total_ms'] / 1e3:.0f} Mpaths/s incl. D2H")
 
 
@@ -660,6 +676,38 @@ def test_f32_mode_matches_the_f64_frame_statistically(rt, gpu_ctx_factory):
         assert abs(y.mean() / x.mean() - 1.0) < 0.03, (arm, x.mean(), y.mean())
     with pytest.raises(rt.Rt1wError):
         ctx.render(64, 64, 4, f32=True, reference_stream=True)
+
+
+def test_f32_mode_against_the_f32_oracle(rt, gpu_ctx_factory):
+    """The expected side of RT1W_PRECISION_F32 that is NOT the product: the literal oracle built with the reference's own precision switch
+    thrown, `type Float = f32` (main.rs:1; oracle/oracle_f32.cpp -> liborc_f32.so), whose block means are committed under
+    tests/golden/oracle_f32_blocks.json (make_golden.py f32).  Same scene, same Philox streams, so most paths are the same paths; what
+    differs is the last f32 ulp here and there (the device evaluates sin / cos / acos / atan2 / ln of a float in single precision, the
+    oracle in 64 bits rounded once; the device's BVH boxes are widened by 1e-5, context_f32.hip) and the paths that ulp sends elsewhere.
+    Bounds: segments per path within 0.5 %, the frame mean within 0.5 %, every block's linear mean within 2.5 % of the oracle's
+    (+ 0.002 absolute for the near-black blocks), no NaN.  random_scene runs the pair walk in this precision too."""
+    gold = json.load(open(os.path.join(HERE, "golden", "oracle_f32_blocks.json")))["cases"]
+    worst = {}
+    for name, g in gold.items():
+        W, H, spp, blk = g["W"], g["H"], g["spp"], g["block"]
+        ctx = gpu_ctx_factory(rt.Scene.reference(g["arm"], build_seed=1, aspect_ratio=g["aspect"]))
+        img, st = ctx.render(W, H, spp, f32=True)
+        assert st["sorted"] & 32 and np.isfinite(img).all(), name
+        if g["arm"] == 0:
+            assert st["sorted"] & 128, "random_scene in f32 did not run the pair-walk kernel"
+            classic, sc_ = ctx.render(W, H, spp, f32=True, classic_walk=True)
+            assert not (sc_["sorted"] & 128)
+            # f32 pair walk against the f32 one-entry-per-step walk: the same boxes gate the same spheres -- the same frame
+            assert sc_["segments"] == st["segments"] and np.array_equal(classic, img), "f32 pair walk differs from the f32 stack walk"
+        want = np.array(g["block_means_bottom_up"])
+        got = img.reshape(H // blk, blk, W // blk, blk, 3).mean(axis=(1, 3))
+        rel = np.abs(got - want) / (np.abs(want) + 0.08)
+        worst[name] = (float(rel.max()), st["segments"] / g["segments"] - 1.0, float(img.mean() / g["mean"] - 1.0))
+        print(name, "worst block %.4f  segments %+.4f  mean %+.4f" % worst[name])
+        assert abs(st["segments"] / g["segments"] - 1.0) < 0.005, (name, st["segments"], g["segments"])
+        assert abs(img.mean() / g["mean"] - 1.0) < 0.005, (name, img.mean(), g["mean"])
+        assert rel.max() < 0.025, (name, float(rel.max()))
+        ctx.close()
 
 
 def test_cli_with_the_reference_stream_prints_the_reference_programs_output(rt, tmp_path):

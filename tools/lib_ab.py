@@ -6,7 +6,8 @@ import sys, os, importlib, hashlib
 sys.path.insert(0, %r)
 rt = importlib.import_module("raytracing-1w_amd")
 out = []
-for arm, aspect, (W, H, spp) in ((0, 1.5, (1200, 800, 48)), (7, None, (800, 800, 48))):
+SPP = int(os.environ.get("AB_SPP", "48"))
+for arm, aspect, (W, H, spp) in ((0, 1.5, (1200, 800, SPP)), (7, None, (800, 800, SPP))):
     ctx = rt.Context(rt.Scene.reference(arm, aspect_ratio=aspect), 0)
     g, s = ctx.render(96, 64, 4)
     h = hashlib.sha256(g.tobytes()).hexdigest()[:10]
