@@ -32,6 +32,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* librt1w.so is built with -fvisibility=hidden: what this header declares is everything it exports (plus three rt1w_internal_* hooks
+ * of its own diagnostics library, csrc/rt1w_internal.h) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define RT1W_OK 0
 #define RT1W_ERR_INVALID (-1)     /* bad argument / bad id / empty BVH (src/bvh.rs:61) */
@@ -345,6 +350,9 @@ int rt1w_debug_texture(rt1w_context* c, int mode, uint32_t tex, const double* in
  * stamp and returns 0 with zeros.  Buckets: see context.hip. */
 int rt1w_debug_stamps(rt1w_context* c, uint64_t out[16], int reset);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@
 #include "rt_wavefront.h"
 #include "scene.h"
 #include "jit.h"
+#include "rt1w_internal.h"
 
 /* context_ref.hip: the plain kernels built with the reference's own random stream (RT1W_RNG_REFERENCE) */
 extern "C" int rt1w_internal_ref_blocks_per_cu(int stack_walk);
@@ -318,6 +319,21 @@ int validate(const rt1w_context* c, const rt1w_render_params* p) {
     return RT1W_OK;
 }
 
+/* the shading-side leaf functions ON THE DEVICE, for known-answer tests of what no artefact of the reference pins:
+ * mode 0 Texture::value(u, v, p) of texture `tex` (texture.rs:40-89); mode 1 Perlin::noise(p) and Perlin::turb(p, 7) of
+ * Perlin table `tex` (perlin.rs:46-86); mode 2 sphere_uv(p) (math.rs:67-71).  in[i] = {u, v, p.x, p.y, p.z}. */
+__global__ void rt_debug_texture_kernel(RtSceneView sc, int mode, uint32_t tex, const double* __restrict__ in, double* __restrict__ out, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u = in[i * 5], v = in[i * 5 + 1];
+    const RtV3 p = rt_v3(in[i * 5 + 2], in[i * 5 + 3], in[i * 5 + 4]);
+    RtV3 r = rt_v3(0.0, 0.0, 0.0);
+    if (mode == 0) r = rt_texture<RtCfgV1>(sc, tex, u, v, p);
+    else if (mode == 1) { r.x = rt_perlin_noise(sc.perlin[tex], p); r.y = rt_perlin_turb(sc.perlin[tex], p, 7); }
+    else { double uu, vv; rt_sphere_uv(p, uu, vv); r.x = uu; r.y = vv; }
+    out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
+}
+
 __global__ void rt_init_counters_kernel(unsigned long long* ctr, unsigned long long next_item) { ctr[0] = next_item; ctr[1] = 0ull; }
 
 bool lane_init(RtLane& l) {
@@ -374,10 +390,10 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
             L.f32 = true; L.jit = true; L.sorted = true; L.cached = false; L.variant = v; L.grid = c->jit32_grid; L.block = RT_SORT_BLOCK;
             return RT1W_OK;
         }
-        const bool sorted = !(p->flags & RT1W_UNSORTED) && (v < 2 || !getenv("RT1W_NO_SLICE_SORT")); /* v >= 2: the slice-end reordering of the stack walks */
+        const bool sorted = !(p->flags & RT1W_UNSORTED); /* v >= 2: the slice-end reordering of the stack walks */
         L.ss = sorted && v >= 2;
         /* sphere scenes: the pair walk (rt_walk_pair.h) in this precision too -- in the kernel that reorders the finished paths */
-        L.pw = L.ss && v == 5 && !(p->flags & RT1W_CLASSIC_WALK) && !getenv("RT1W_CLASSIC_WALK") && rt1w_internal_f32_pw(c->f32_scene, (unsigned)RT_PW_SS_STACK) == 1;
+        L.pw = L.ss && v == 5 && !(p->flags & RT1W_CLASSIC_WALK) && rt1w_internal_f32_pw(c->f32_scene, (unsigned)RT_PW_SS_STACK) == 1;
         int& g = c->f32_grid[v][L.pw ? 2 : (sorted ? 1 : 0)];
         if (!g) {
             hipDeviceProp_t prop;
@@ -412,16 +428,16 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     L.jit = c->jit_fn != nullptr && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED | RT1W_LDS_NODES)) && !(p->flags >> 8);
     if (L.jit) { L.sorted = true; L.cached = false; L.grid = c->jit_grid; L.block = RT_SORT_BLOCK; return RT1W_OK; }
     /* sphere scenes: the pair walk (same frames, bit for bit), unless the caller asks for the one-entry-per-step walk */
-    if (c->pw_ok && variant == 5 && !(p->flags & (RT1W_CLASSIC_WALK | RT1W_LDS_NODES | RT1W_WAVEFRONT)) && !getenv("RT1W_CLASSIC_WALK")) {
+    if (c->pw_ok && variant == 5 && !(p->flags & (RT1W_CLASSIC_WALK | RT1W_LDS_NODES | RT1W_WAVEFRONT))) {
         L.pw = true; L.sorted = false; L.cached = false; L.grid = c->pw_grid; L.block = RT_BLOCK;
-        L.ss = c->pw_ss_grid > 0 && !(p->flags & RT1W_UNSORTED) && !getenv("RT1W_NO_SLICE_SORT");
+        L.ss = c->pw_ss_grid > 0 && !(p->flags & RT1W_UNSORTED);
         if (L.ss) L.grid = c->pw_ss_grid;
         return RT1W_OK;
     }
     L.sorted = g_kernels_sorted[variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
-    L.sphere_media = !L.sorted && !L.cached && c->sphere_media && g_kernels_sphere_media[variant] != nullptr && !(p->flags & RT1W_CLASSIC_WALK) && !getenv("RT1W_CLASSIC_WALK");
-    L.ss = !L.sorted && !L.cached && g_kernels_ss[L.sphere_media ? 1 : 0][variant] != nullptr && !(p->flags & RT1W_UNSORTED) && !getenv("RT1W_NO_SLICE_SORT");
+    L.sphere_media = !L.sorted && !L.cached && c->sphere_media && g_kernels_sphere_media[variant] != nullptr && !(p->flags & RT1W_CLASSIC_WALK);
+    L.ss = !L.sorted && !L.cached && g_kernels_ss[L.sphere_media ? 1 : 0][variant] != nullptr && !(p->flags & RT1W_UNSORTED);
     L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.ss ? c->grid_ss[L.sphere_media ? 1 : 0][variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant])));
     L.block = L.sorted ? RT_SORT_BLOCK : RT_BLOCK;
     return RT1W_OK;
@@ -1127,6 +1143,30 @@ int rt1w_debug_aabb(rt1w_context* c, const double* in, int* out_literal, int* ou
     if (d1) (void)hipFree(d1);
     return rc;
 }
+
+int rt1w_debug_texture(rt1w_context* c, int mode, uint32_t tex, const double* in, double* out, uint64_t n) {
+    if (!c || !in || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (n == 0) return RT1W_OK;
+    RtSceneView view;
+    memcpy(&view, &c->view, sizeof view);
+    if (mode < 0 || mode > 2) { rt1w::set_error("unknown mode"); return RT1W_ERR_INVALID; }
+    if (mode == 0 && tex >= view.n_textures) { rt1w::set_error("bad texture id"); return RT1W_ERR_INVALID; }
+    if (mode == 1 && view.perlin == nullptr) { rt1w::set_error("the scene has no Perlin table"); return RT1W_ERR_INVALID; }
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
+    double *din = nullptr, *dout = nullptr;
+    int rc = RT1W_OK;
+    if (!hip_ok(hipMalloc((void**)&din, n * 5 * sizeof(double)), "hipMalloc") || !hip_ok(hipMalloc((void**)&dout, n * 3 * sizeof(double)), "hipMalloc")) rc = RT1W_ERR_NOMEM;
+    if (rc == RT1W_OK) {
+        (void)hipMemcpy(din, in, n * 5 * sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(rt_debug_texture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, view, mode, tex, din, dout, (unsigned long long)n);
+        if (!hip_ok(hipGetLastError(), "launch") || !hip_ok(hipDeviceSynchronize(), "texture probe kernel")) rc = RT1W_ERR_DEVICE;
+        else (void)hipMemcpy(out, dout, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
 
 int rt1w_debug_stamps(rt1w_context* c, uint64_t out[16], int reset) {
     if (!c || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }

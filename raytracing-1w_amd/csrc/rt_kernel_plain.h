@@ -18,7 +18,9 @@ struct RtPwView { int unused; };
 #define RT_PW_SS_PARTS 3
 #endif
 #ifndef RT_CAM_AT_USE
-#define RT_CAM_AT_USE 1 /* rt_render_ss_body reads the camera block by scalar loads where a path begins instead of holding it across the loop */
+#define RT_CAM_AT_USE 0 /* 1: rt_render_ss_body reads the camera block by scalar loads where a path begins instead of holding it across the loop
+                            (its 24 doubles sit in SGPRs spilled to VGPR lanes and scratch).  Measured at 128 spp, kernel Mpaths/s: random_scene
+                            933 -> 904, final_scene 336 -> 334 (the scalar loads' s_waitcnt also waits for the LDS): off */
 #endif
 #ifndef RT_PW_BOX_STEPS
 #define RT_PW_BOX_STEPS 6 /* inner records a lane visits per vote */

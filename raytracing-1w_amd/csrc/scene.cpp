@@ -1,6 +1,7 @@
 /* scene.cpp -- scene half of the C ABI (include/rt1w.h): constructors, BVH build,
  * camera, flatten.  Reference citations are paths under /root/reference/src. */
 #include "scene.h"
+#include "rt1w_internal.h"
 
 #include <algorithm>
 #include <cstring>
@@ -448,6 +449,7 @@ static int add_material(rt1w_scene* s, uint32_t kind, uint32_t tex, double d0, d
 extern "C" {
 
 const char* rt1w_last_error(void) { return g_error.c_str(); }
+void rt1w_internal_set_error(const char* msg) { set_error(msg ? msg : ""); } /* rt1w_internal.h */
 const char* rt1w_version(void) { return "rt1w-mi355x 0.1 (gfx950, f64, philox4x32-10)"; }
 
 int rt1w_scene_create(uint64_t build_seed, rt1w_scene** out) {

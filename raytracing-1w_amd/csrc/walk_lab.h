@@ -1,5 +1,5 @@
-/* walk_lab.h -- entry points of the trace-only harness (walk_lab.hip).  Diagnostics: not part of include/rt1w.h, no render
- * entry point reaches them; tools/walk_lab.py and the GPU tests bind them with ctypes. */
+/* walk_lab.h -- entry points of the trace-only harness (walk_lab.hip).  Diagnostics: a library of their own (librt1w_lab.so, linked
+ * against librt1w.so), not part of include/rt1w.h; tools/walk_lab.py and the GPU tests bind them with ctypes. */
 #ifndef RT1W_WALK_LAB_H
 #define RT1W_WALK_LAB_H
 
@@ -10,6 +10,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 typedef struct rt1w_lab rt1w_lab;
 
@@ -29,6 +30,7 @@ int rt1w_lab_set_rays(rt1w_lab* l, const double* rays, uint64_t n);
 int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats, double* out_t, uint32_t* out_prim, uint32_t* out_flags,
                    double* ms_best, uint64_t stats_out[8]);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -43,14 +43,15 @@
 #include "scene.h"
 #include "walk_lab.h"
 
-extern "C" const void* rt1w_internal_view(const rt1w_context* c);
-extern "C" int rt1w_internal_device(const rt1w_context* c);
+#include "rt1w_internal.h"
+/* this file is librt1w_lab.so: it reaches the product library through its exported entries only */
+namespace rt1wlab { inline void set_error(const std::string& m) { rt1w_internal_set_error(m.c_str()); } }
 
 namespace {
 
 bool lab_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
-    rt1w::set_error(std::string("walk lab: ") + what + ": " + hipGetErrorString(e));
+    rt1wlab::set_error(std::string("walk lab: ") + what + ": " + hipGetErrorString(e));
     return false;
 }
 
@@ -488,23 +489,6 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w0q(RtSceneView sc, con
         atomicAdd(&stats[0], steps);
         if ((threadIdx.x & 63u) == 0u) atomicAdd(&stats[1], wave_steps);
     }
-}
-
-/* ------------------------------------------------------------------------------------- texture probe -- */
-
-/* the shading-side leaf functions ON THE DEVICE, for known-answer tests of what no artefact of the reference pins:
- * mode 0 Texture::value(u, v, p) of texture `tex` (texture.rs:40-89); mode 1 Perlin::noise(p) and Perlin::turb(p, 7) of
- * Perlin table `tex` (perlin.rs:46-86); mode 2 sphere_uv(p) (math.rs:67-71).  in[i] = {u, v, p.x, p.y, p.z}. */
-__global__ void lab_texture_kernel(RtSceneView sc, int mode, uint32_t tex, const double* __restrict__ in, double* __restrict__ out, unsigned long long n) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double u = in[i * 5], v = in[i * 5 + 1];
-    const RtV3 p = rt_v3(in[i * 5 + 2], in[i * 5 + 3], in[i * 5 + 4]);
-    RtV3 r = rt_v3(0.0, 0.0, 0.0);
-    if (mode == 0) r = rt_texture<RtCfgV1>(sc, tex, u, v, p);
-    else if (mode == 1) { r.x = rt_perlin_noise(sc.perlin[tex], p); r.y = rt_perlin_turb(sc.perlin[tex], p, 7); }
-    else { double uu, vv; rt_sphere_uv(p, uu, vv); r.x = uu; r.y = vv; }
-    out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
 }
 
 /* --------------------------------------------------------------------------------------- gather probe -- */
@@ -1000,10 +984,10 @@ bool lab_upload(T** dst, const std::vector<T>& v) {
 extern "C" {
 
 int rt1w_lab_create(rt1w_context* c, const rt1w_scene* s, rt1w_lab** out) {
-    if (!c || !s || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
-    if (!s->committed) { rt1w::set_error("scene not committed"); return RT1W_ERR_STATE; }
+    if (!c || !s || !out) { rt1wlab::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!s->committed) { rt1wlab::set_error("scene not committed"); return RT1W_ERR_STATE; }
     rt1w_lab* l = new (std::nothrow) rt1w_lab();
-    if (!l) { rt1w::set_error("out of memory"); return RT1W_ERR_NOMEM; }
+    if (!l) { rt1wlab::set_error("out of memory"); return RT1W_ERR_NOMEM; }
     l->ctx = c;
     memcpy(&l->view, rt1w_internal_view(c), sizeof(RtSceneView));
     l->device = rt1w_internal_device(c);
@@ -1091,15 +1075,15 @@ void rt1w_lab_destroy(rt1w_lab* l) {
 }
 
 int rt1w_lab_info(const rt1w_lab* l, uint32_t out[4]) {
-    if (!l || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!l || !out) { rt1wlab::set_error("null argument"); return RT1W_ERR_INVALID; }
     out[0] = l->w1_ok ? 1u : 0u; out[1] = l->n_inner; out[2] = l->n_groups; out[3] = (uint32_t)l->variant;
-    if (!l->w1_ok) rt1w::set_error("W1 not available for this scene: " + l->w1_why);
+    if (!l->w1_ok) rt1wlab::set_error("W1 not available for this scene: " + l->w1_why);
     return RT1W_OK;
 }
 
 /* out_ms[4] = kernel ms of {own record, quad-shared} x {independent, dependent} indices; grid = blocks_per_cu x CUs of 256 threads */
 int rt1w_lab_gather_probe(rt1w_lab* l, uint32_t iters, uint32_t blocks_per_cu, double out_ms[4], uint64_t* records_per_launch) {
-    if (!l || !out_ms) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!l || !out_ms) { rt1wlab::set_error("null argument"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const int grid = l->cus * (int)(blocks_per_cu ? blocks_per_cu : 4u);
     for (int v = 0; v < 4; ++v) {
@@ -1122,32 +1106,9 @@ int rt1w_lab_gather_probe(rt1w_lab* l, uint32_t iters, uint32_t blocks_per_cu, d
     return RT1W_OK;
 }
 
-int rt1w_debug_texture(rt1w_context* c, int mode, uint32_t tex, const double* in, double* out, uint64_t n) {
-    if (!c || !in || !out) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
-    if (n == 0) return RT1W_OK;
-    RtSceneView view;
-    memcpy(&view, rt1w_internal_view(c), sizeof view);
-    if (mode < 0 || mode > 2) { rt1w::set_error("unknown mode"); return RT1W_ERR_INVALID; }
-    if (mode == 0 && tex >= view.n_textures) { rt1w::set_error("bad texture id"); return RT1W_ERR_INVALID; }
-    if (mode == 1 && view.perlin == nullptr) { rt1w::set_error("the scene has no Perlin table"); return RT1W_ERR_INVALID; }
-    if (!lab_ok(hipSetDevice(rt1w_internal_device(c)), "hipSetDevice")) return RT1W_ERR_DEVICE;
-    double *din = nullptr, *dout = nullptr;
-    int rc = RT1W_OK;
-    if (!lab_ok(hipMalloc((void**)&din, n * 5 * sizeof(double)), "hipMalloc") || !lab_ok(hipMalloc((void**)&dout, n * 3 * sizeof(double)), "hipMalloc")) rc = RT1W_ERR_NOMEM;
-    if (rc == RT1W_OK) {
-        (void)hipMemcpy(din, in, n * 5 * sizeof(double), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(lab_texture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, view, mode, tex, din, dout, (unsigned long long)n);
-        if (!lab_ok(hipGetLastError(), "launch") || !lab_ok(hipDeviceSynchronize(), "texture probe kernel")) rc = RT1W_ERR_DEVICE;
-        else (void)hipMemcpy(out, dout, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
-    }
-    if (din) (void)hipFree(din);
-    if (dout) (void)hipFree(dout);
-    return rc;
-}
-
 int rt1w_lab_dump_rays(rt1w_lab* l, const rt1w_render_params* p, uint32_t n_bounces, double* out_host) {
-    if (!l || !p || !out_host || n_bounces == 0u) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
-    if (p->tile_w == 0 || p->tile_h == 0 || p->x0 + p->tile_w > p->width || p->y0 + p->tile_h > p->height || p->spp == 0) { rt1w::set_error("bad tile"); return RT1W_ERR_INVALID; }
+    if (!l || !p || !out_host || n_bounces == 0u) { rt1wlab::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (p->tile_w == 0 || p->tile_h == 0 || p->x0 + p->tile_w > p->width || p->y0 + p->tile_h > p->height || p->spp == 0) { rt1wlab::set_error("bad tile"); return RT1W_ERR_INVALID; }
     RtFrame f; memset(&f, 0, sizeof f);
     f.width = p->width; f.height = p->height; f.x0 = p->x0; f.y0 = p->y0; f.tile_w = p->tile_w; f.tile_h = p->tile_h;
     f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth ? p->max_depth : 50u; f.global_seed = p->global_seed;
@@ -1167,7 +1128,7 @@ int rt1w_lab_dump_rays(rt1w_lab* l, const rt1w_render_params* p, uint32_t n_boun
 }
 
 int rt1w_lab_set_rays(rt1w_lab* l, const double* rays, uint64_t n) {
-    if (!l || !rays || n == 0) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
+    if (!l || !rays || n == 0) { rt1wlab::set_error("null argument"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     if (l->d_rays) { (void)hipFree(l->d_rays); l->d_rays = nullptr; }
     if (l->d_hits) { (void)hipFree(l->d_hits); l->d_hits = nullptr; }
@@ -1180,15 +1141,15 @@ int rt1w_lab_set_rays(rt1w_lab* l, const double* rays, uint64_t n) {
 /* params: [0] refill_idle (lanes), [1] leaf_votes (W1, W2), [2] blocks per CU (0: the occupancy query's), [3] box steps per vote (W2) */
 int rt1w_lab_trace(rt1w_lab* l, int mode, const uint32_t params[4], int repeats, double* out_t, uint32_t* out_prim, uint32_t* out_flags,
                    double* ms_best, uint64_t stats_out[8]) {
-    if (!l || !l->d_rays) { rt1w::set_error("no rays set"); return RT1W_ERR_STATE; }
-    if (mode == 1 && !l->w1_ok) { rt1w::set_error("W1 not available for this scene: " + l->w1_why); return RT1W_ERR_UNSUPPORTED; }
-    if (mode == 2 && (!l->w1_ok || l->n_inner > LAB_LDS_INNER || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with LDS-resident inner records: scene too big or W1 unavailable"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1w::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1w::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode == 6 && !l->w2_ok) { rt1w::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
-    if ((mode == 11 || mode == 13) && !l->w4_ok) { rt1w::set_error("W4: more than 8192 nodes, a deeper stack than the experiment's, or a medium whose boundary is not a bare sphere"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode == 12 && !l->sphere_media) { rt1w::set_error("W0c of the sphere-media kernels: not such a scene"); return RT1W_ERR_UNSUPPORTED; }
-    if (mode < 0 || mode > 13) { rt1w::set_error("unknown walk"); return RT1W_ERR_INVALID; }
+    if (!l || !l->d_rays) { rt1wlab::set_error("no rays set"); return RT1W_ERR_STATE; }
+    if (mode == 1 && !l->w1_ok) { rt1wlab::set_error("W1 not available for this scene: " + l->w1_why); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 2 && (!l->w1_ok || l->n_inner > LAB_LDS_INNER || l->stack_need > LAB_LDS_STACK)) { rt1wlab::set_error("W1 with LDS-resident inner records: scene too big or W1 unavailable"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 4 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK)) { rt1wlab::set_error("W1 with f32 inner boxes: W1 unavailable or tree too deep for the experiment's stack"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 5 && (!l->w1_ok || l->stack_need > LAB_LDS_STACK || l->n_inner > LAB_LDS_INNER)) { rt1wlab::set_error("W1c with LDS-resident inner records: not for this scene"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 6 && !l->w2_ok) { rt1wlab::set_error("phased walk: the scene needs a deeper stack than RT_W2_STACK"); return RT1W_ERR_UNSUPPORTED; }
+    if ((mode == 11 || mode == 13) && !l->w4_ok) { rt1wlab::set_error("W4: more than 8192 nodes, a deeper stack than the experiment's, or a medium whose boundary is not a bare sphere"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode == 12 && !l->sphere_media) { rt1wlab::set_error("W0c of the sphere-media kernels: not such a scene"); return RT1W_ERR_UNSUPPORTED; }
+    if (mode < 0 || mode > 13) { rt1wlab::set_error("unknown walk"); return RT1W_ERR_INVALID; }
     if (!lab_ok(hipSetDevice(l->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     const uint32_t refill = params && params[0] ? params[0] : 16u;
     const uint32_t votes = params && params[1] ? params[1] : 24u;

@@ -26,6 +26,20 @@ def test_library_exports_every_declared_symbol(rt):
         assert hasattr(lib, n), f"{n} is declared in include/rt1w.h but not exported"
 
 
+def test_library_exports_nothing_else(rt):
+    """librt1w.so is built with -fvisibility=hidden and a linker version script (csrc/librt1w.map): its dynamic symbol table holds the
+    entries include/rt1w.h declares plus the three hooks of csrc/rt1w_internal.h (for the diagnostics library librt1w_lab.so) and
+    nothing else -- no C++ internals, no kernel host stubs, no unprefixed helpers, no laboratory (`rt1w_lab_*` live in librt1w_lab.so)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rt.LIB_PATH]).decode()
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.strip()})
+    internal = ["rt1w_internal_device", "rt1w_internal_set_error", "rt1w_internal_view"]
+    assert exported == sorted(set(declared_functions()) | set(internal)), sorted(set(exported) ^ (set(declared_functions()) | set(internal)))
+    lab = os.path.join(os.path.dirname(rt.LIB_PATH), "librt1w_lab.so")
+    lab_syms = subprocess.check_output(["nm", "-D", "--defined-only", lab]).decode()
+    assert "rt1w_lab_trace" in lab_syms and "rt1w_lab_" not in out
+
+
 def test_integration_rust_block_declares_every_entry_of_the_header():
     """INTEGRATION.md section 2 claims to mirror include/rt1w.h one to one: the `extern "C"` block must name exactly the
     functions the header declares, and its #[repr(C)] structs must have the header's fields in the header's order."""

@@ -1,5 +1,5 @@
 """Plain sliced stack-walk kernel against the same kernel with the finished paths reordered across the workgroup at the end of every
-slice (the default for sphere-media scenes; RT1W_NO_SLICE_SORT selects the plain kernel; rt_kernel_plain.h: rt_render_ss_body): kernel Mpaths/s, frames compared bit for bit.
+slice (the default for sphere-media scenes; the flag RT1W_UNSORTED selects the plain kernel; rt_kernel_plain.h: rt_render_ss_body): kernel Mpaths/s, frames compared bit for bit.
   python3 tools/ss_ab.py [arm] [W] [H] [spp] [--sah]"""
 import importlib
 import os
@@ -16,16 +16,11 @@ if "--sah" in sys.argv:
     sc.set_bvh_build(True)
     sc.set_walk_order(1)
 ctx = rt.Context(sc, 0)
-os.environ.pop("RT1W_NO_SLICE_SORT", None)
 ctx.render(W, H, 4)
 ref = None
 for rep in range(3):
     for mode in ("plain", "slice-sorted"):
-        if mode == "plain":
-            os.environ["RT1W_NO_SLICE_SORT"] = "1"
-        else:
-            os.environ.pop("RT1W_NO_SLICE_SORT", None)
-        img, st = ctx.render(W, H, spp)
+        img, st = ctx.render(W, H, spp, unsorted=(mode == "plain"), classic_walk="--classic" in sys.argv)
         if ref is None:
             ref = img
         print(f"{mode:13s} V{st['variant']} flags {st['sorted']:4d}: {W * H * spp / st['kernel_ms'] / 1e3:8.1f} Mpaths/s kernel {st['kernel_ms']:8.2f} ms  segments {st['segments']}  "

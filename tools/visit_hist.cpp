@@ -38,12 +38,12 @@ int main(int argc, char** argv) {
             RtPath p; rt_path_begin(sc, f, x, y, k, p);
             while (p.alive) {
                 segs += p.depth_left != 0u;
-                RtTrace tr = ((mode & 2) || mode == 5) ? rt_path_trace<RtCfgV4>(sc, ns, p, stk) : rt_path_trace<RtCfgV3>(sc, ns, p, stk);
+                RtTrace tr = ((mode < 4 && (mode & 2)) || mode == 5) ? rt_path_trace<RtCfgV4>(sc, ns, p, stk) : rt_path_trace<RtCfgV3>(sc, ns, p, stk);
                 rt_path_shade<RtCfgV3>(sc, p, tr);
             }
         }
         unsigned long long tot = 0; for (int i = 0; i < 16; i++) tot += g_hist[i];
-        printf("arm %d %-9s%-9s nodes %5u: %.2f visits/segment:", arm, mode >= 4 ? "best-axis" : (mode & 1) ? "SAH" : "reference", ((mode & 2) || mode == 5) ? "+near-far" : "", inf.n_nodes, (double)tot / segs);
+        printf("arm %d %-9s%-9s nodes %5u: %.2f visits/segment:", arm, mode >= 4 ? "best-axis" : (mode & 1) ? "SAH" : "reference", ((mode < 4 && (mode & 2)) || mode == 5) ? "+near-far" : "", inf.n_nodes, (double)tot / segs);
         for (int i = 0; i < 11; i++) if (g_hist[i]) printf(" %s %.2f", names[i], (double)g_hist[i] / segs);
         printf("\n");
         rt1w_scene_destroy(s);
