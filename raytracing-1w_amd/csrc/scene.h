@@ -59,7 +59,7 @@ struct rt1w_scene {
     bool media_bare_spheres = false; /* every ConstantMedium's boundary is a bare Sphere node (the kernels of RtCfgSphereMedia) */
     uint32_t walk_order = 0; /* RT1W_WALK_* */
     uint32_t walk_annotated = 0; /* BVH nodes that carry an order annotation (0: the plain kernels serve) */
-    uint32_t bvh_build = 0;  /* RT1W_BVH_* */
+    uint32_t bvh_build = RT1W_BVH_BEST_AXIS;  /* RT1W_BVH_*: what rt1w_scene_commit flattens with (include/rt1w.h says why) */
     std::vector<int32_t> bvh_topology; /* RT1W_BVH_SAH / RT1W_BVH_BEST_AXIS: the rebuilt trees, see rt1w_scene_get_bvh_topology */
     /* every `BVHNode::new` call of the host (rt1w_hittable_bvh, an AABox's sides): root hittable id -> the objects in the order they
      * were handed over (what RT1W_BVH_BEST_AXIS re-runs the reference's build rule on, bvh.rs:84-87) */

@@ -51,10 +51,12 @@ class OracleBuilt(orc.OracleScene):
 class Dual:
     """Every method returns a (product id, oracle id) pair."""
 
-    def __init__(self, build_seed):
+    def __init__(self, build_seed, best_axis=True):
         self.rt = orc.rt()
         self.p = self.rt.Scene(build_seed)
         self.o = A.orcb_new(build_seed)
+        self.best_axis = best_axis  # the product's default build (RT1W_BVH_BEST_AXIS); False: both sides draw the axes (RT1W_BVH_REFERENCE)
+        A.orc_set_bvh_axis_rule(1 if best_axis else 0)
         self._img = []
 
     def rng_f64(self):
@@ -104,22 +106,25 @@ class Dual:
         self.p.set_background(background)
         self.p.set_camera(*cam)
         self.p.commit()
+        if not self.best_axis:
+            self.p.set_bvh_build("reference")
         A.orcb_set_world(self.o, world[1])
         arr = (C.c_int * max(1, len(lights)))(*[l[1] for l in lights])
         A.orcb_set_lights(self.o, arr, len(lights))
         A.orcb_set_background(self.o, *map(float, background))
         A.orcb_set_camera(self.o, _d3(cam[0]), _d3(cam[1]), _d3(cam[2]), *[float(x) for x in cam[3:]])
         h = A.orcb_finish(self.o)
+        A.orc_set_bvh_axis_rule(0)
         self.o = None
         return self.p, OracleBuilt(h)
 
 
-def random_scene_pair(seed, n_objects=None):
+def random_scene_pair(seed, n_objects=None, best_axis=True):
     """A random but well-formed scene graph: every primitive, wrapper nesting up to 3, media with sphere / box /
     wrapped-box boundaries, nested BVHs (incl. 1- and 2-element ones), textures of every kind, 0-3 lights incl. kinds
     that keep the trait defaults."""
     g = np.random.default_rng(seed)
-    d = Dual(int(g.integers(1, 1 << 30)))
+    d = Dual(int(g.integers(1, 1 << 30)), best_axis)
     img = g.integers(0, 256, (8, 16, 3), dtype=np.uint8)
 
     def tex(depth=0):

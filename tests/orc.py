@@ -85,9 +85,10 @@ class OracleScene:
 
     lib = A  # class default (subclasses that wrap a ready handle); instances made with refstream=True use REF
 
-    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False, best_axis=False, f32=False):
-        """best_axis: BVHNode::new with the axis of bvh.rs:84 chosen by the cost of its median split instead of drawn (the oracle's own
-        statement of the product's opt-in RT1W_BVH_BEST_AXIS; oracle.cpp: BVHNode::best_axis)."""
+    def __init__(self, arm, build_seed=1, aspect_ratio=None, earth=None, refstream=False, best_axis=True, f32=False):
+        """best_axis (default, because it is the product's default build, RT1W_BVH_BEST_AXIS): BVHNode::new with the axis of bvh.rs:84
+        chosen by the cost of its median split (the oracle's own statement of the rule, oracle.cpp: BVHNode::best_axis); False: the
+        axis drawn from the build seed, as the reference draws it from its entropy-seeded generator (RT1W_BVH_REFERENCE)."""
         self.lib = REF if refstream else (F32 if f32 else A)
         self.f32 = bool(f32)  # the build with type Float = f32: frames come back as float32 and are widened here
         if aspect_ratio is None:

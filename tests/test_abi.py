@@ -186,7 +186,10 @@ def test_specialised_kernels_of_the_reference_arms_are_built(rt):
         keys[arm] = key
     assert keys[5] != keys[6] and keys[5] != keys[4]
     assert rt.Scene.reference(5, build_seed=1).kernel_key() == keys[5]          # deterministic
-    assert rt.Scene.reference(5, build_seed=2).kernel_key() != keys[5]          # another tree, another kernel
+    # the default build chooses its split axes (RT1W_BVH_BEST_AXIS): the tree -- and the kernel made for it -- no longer depends on what
+    # the build seed draws; with the axes drawn (RT1W_BVH_REFERENCE) another seed is another tree, another kernel
+    assert rt.Scene.reference(5, build_seed=2).kernel_key() == keys[5]
+    assert rt.Scene.reference(5, build_seed=2).set_bvh_build("reference").kernel_key() != rt.Scene.reference(5, build_seed=1).set_bvh_build("reference").kernel_key()
     for arm in (0, 7):
         with pytest.raises(rt.Rt1wError) as e:
             rt.Scene.reference(arm, build_seed=1).kernel_key()

@@ -428,8 +428,8 @@ def test_scene_specialised_kernels_are_bit_identical(rt, gpu_ctx_factory, tmp_pa
         assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), arm
         f, _ = orc.flat_render(sc, W, H, spp, chunk=sa["chunk"])
         assert np.array_equal(a, f, equal_nan=True), arm
-    # (2) another build seed = another tree: cache miss, compile, then a hit from the user cache
-    sc = rt.Scene.reference(5, build_seed=7)
+    # (2) another tree (the axes of bvh.rs:84 drawn from another build seed, RT1W_BVH_REFERENCE): cache miss, compile, then a hit from the user cache
+    sc = rt.Scene.reference(5, build_seed=7).set_bvh_build("reference")
     ctx = gpu_ctx_factory(sc)
     assert not ctx.specialised()
     with pytest.raises(rt.Rt1wError) as e:

@@ -15,7 +15,7 @@ NODE = np.dtype([('kind', '<u4'), ('skip', '<u4'), ('d', '<f8', 6), ('b', '<u4')
 
 
 def scenes(rt):
-    out = [("cornell", rt.Scene.reference(5, build_seed=1)), ("cornell_seed3", rt.Scene.reference(5, build_seed=3)),
+    out = [("cornell", rt.Scene.reference(5, build_seed=1)), ("cornell_seed3_drawn_axes", rt.Scene.reference(5, build_seed=3).set_bvh_build("reference")),
            ("cornel_smoke", rt.Scene.reference(6, build_seed=1)), ("simple_light", rt.Scene.reference(4, build_seed=1)),
            ("two_perlin", rt.Scene.reference(2, build_seed=1))]
     n = 0
