@@ -13,8 +13,9 @@ Workloads (--workload; BASELINE.json configs, reference lines under /root/refere
 
   N = 1  one GPU renders the whole frame into a pinned host frame (rt1w_render, RT1W_OUT_FRAME).  The c3 line also carries
          `other_configs`: C2 at full size and C4 at 400 spp measured the same way (D2H-inclusive Mpaths/s, kernel ms,
-         segments/path, roofline block), on the reference's trees (c2, c4) and on the opt-in SAH trees with near-far
-         order (c2_sah, c4_sah), so every single-GPU BASELINE config has one driver-timed number per tree.
+         segments/path, roofline block), each on three trees: the default build (c2, c4: BVHNode::new with the split axis chosen,
+         RT1W_BVH_BEST_AXIS), the axes drawn from build seed 1 (c2_drawn_axes, c4_drawn_axes: rounds 1-3's default) and the opt-in
+         SAH trees with near-far order (c2_sah, c4_sah), so every single-GPU BASELINE config has one driver-timed number per tree.
   N > 1  the SAME job shape, image-tiled over the GPUs of one node as the north star says: 16-row strips dealt round-robin
          (sharding.interleaved_tile; one launch per GPU renders all of its strips), every rank's device->host copy writes
          its strips straight into ONE shared pinned host frame (sharding.SharedFrame) -- the host gather, inside the
@@ -23,6 +24,10 @@ Workloads (--workload; BASELINE.json configs, reference lines under /root/refere
          and constant camera -- side = 16N*round(600*sqrt(N)/16N): 600, 864, 1216, 1664, a whole number of 16-row strips per
          GPU -- so every GPU keeps C3's 3.6e8 paths per step within 4 %.  --strong keeps 600x600 for all N.
          c2 / c4 / c5 are one fixed frame each (BASELINE: "tiled across 8 MI355X"): strong scaling.
+         The default N > 1 line (c3, weak) also carries `other_configs` = BASELINE's two multi-GPU configs as strong-scaling jobs of
+         the same N ranks: `c5_strong` (Cornell 3840x2160, 1000 spp per step instead of 10 000) and `c4_strong` (final_scene 800x800,
+         400 spp instead of 10 000), each with the D2H-inclusive rate, per-rank kernel ms (min / max: the strips' load balance),
+         `n_ranks_seen`, and `gathered_frame_equals_single_gpu_frame` under --check-frame.
 
 Launching.  `python bench.py --gpus N` with no launcher around it starts its own N rank processes (the replacement of rayon's
 all-core into_par_iter, main.rs:957-963): fresh children created BEFORE this process touches the GPU or imports torch,
@@ -60,8 +65,12 @@ WORKLOADS = {
 }
 # carried by the N = 1 c3 line: (entry, workload, spp, bvh, walk order).  The *_sah entries run the opt-in SAH trees (checked against the
 # literal oracle on the same topology, tests/test_bvh_build.py) with the near child first where that preserves the result
-OTHER_CONFIGS = (("c2", "c2", 500, "reference", "reference"), ("c4", "c4", 400, "reference", "reference"),
+OTHER_CONFIGS = (("c2", "c2", 500, "best_axis", "reference"), ("c4", "c4", 400, "best_axis", "reference"),
+                 ("c2_drawn_axes", "c2", 500, "reference", "reference"), ("c4_drawn_axes", "c4", 400, "reference", "reference"),
                  ("c2_sah", "c2", 500, "sah", "near-far"), ("c4_sah", "c4", 400, "sah", "near-far"))
+# carried by the default N > 1 line: BASELINE's two multi-GPU configs, tiled over the same ranks (entry, workload, spp per step, steps)
+OTHER_CONFIGS_MULTI = (("c5_strong", "c5", 1000, 2), ("c4_strong", "c4", 400, 3))
+DEFAULT_BVH = "best_axis"
 
 
 # --------------------------------------------------------------------------------------------------------- launcher --
@@ -74,14 +83,30 @@ def free_port():
     return p
 
 
-def launch_ranks(n, argv, script=None, env_extra=None, timeout=None):
+LAUNCH_TIMEOUT_S = 3300.0   # a rank stuck in the rendezvous (or anywhere else) ends the job with exit code 124 instead of hanging it
+
+
+def launch_ranks(n, argv, script=None, env_extra=None, timeout=LAUNCH_TIMEOUT_S):
     """Start `n` rank processes of `script` (default: this file) with `argv`, one per GPU, and wait for them.
     Must be called from a process that has not initialised the GPU (nothing here imports torch or the HIP library);
     the children are fresh interpreters (fork + exec of python before any GPU call -- never a re-exec of a process that
-    holds the GPU).  Returns (exit code, rank 0's stdout).  A failing rank ends the others."""
+    holds the GPU).  Returns (exit code, rank 0's stdout).  A failing rank ends the others; after `timeout` seconds all are killed (124).
+    Rank 0's stdout goes to a temporary FILE (a pipe would block the rank once ~64 KB are unread); the other ranks' stdout is
+    sent to this process's stderr, so that whatever a failing rank prints reaches the caller."""
+    import tempfile
     script = script or os.path.abspath(__file__)
     port = free_port()
     procs = []
+    out_file = tempfile.TemporaryFile()
+
+    def die_with_parent():   # in the child, between fork and exec: a launcher that is killed takes its ranks with it
+        try:
+            import ctypes
+            import signal
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)   # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -89,17 +114,14 @@ def launch_ranks(n, argv, script=None, env_extra=None, timeout=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if env_extra:
             env.update(env_extra)
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out_file if r == 0 else sys.stderr,
+                                      preexec_fn=die_with_parent))
     t_end = None if timeout is None else time.time() + timeout
     rc = 0
-    out0 = None
     live = set(range(n))
     while live:
         for r in sorted(live):
             p = procs[r]
-            if r == 0 and out0 is None and p.poll() is not None:
-                out0 = p.stdout.read().decode()
             if p.poll() is not None:
                 live.discard(r)
                 if p.returncode != 0 and rc == 0:
@@ -108,20 +130,26 @@ def launch_ranks(n, argv, script=None, env_extra=None, timeout=None):
                     for q in procs:
                         if q.poll() is None:
                             q.terminate()   # the exact children started above, by pid
-        if t_end is not None and time.time() > t_end:
+        if live and t_end is not None and time.time() > t_end:
             rc = rc or 124
+            print(f"bench.py: ranks {sorted(live)} still running after {timeout:.0f} s; killing them", file=sys.stderr)
             for q in procs:
                 if q.poll() is None:
                     q.kill()
             break
         time.sleep(0.05)
-    if out0 is None:
-        try:
-            out0 = procs[0].stdout.read().decode()
-        except Exception:
-            out0 = ""
     for q in procs:
         q.wait()
+    # a rank that was stopped (or died) could not remove the shared host frames it had created: their names carry this launch's port and pid
+    try:
+        for f in os.listdir("/dev/shm"):
+            if f.startswith(f"rt1w_bench_{port}_{os.getpid()}"):
+                os.unlink(os.path.join("/dev/shm", f))
+    except OSError:
+        pass
+    out_file.seek(0)
+    out0 = out_file.read().decode(errors="replace")
+    out_file.close()
     return rc, out0
 
 
@@ -147,8 +175,7 @@ class GpuBackend:
 
     def scene(self, arm, aspect, bvh, walk_order):
         sc = self.rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
-        if bvh == "sah":
-            sc.set_bvh_build(True)
+        sc.set_bvh_build(bvh)            # "best_axis" (the library's default), "reference" (axes drawn from build seed 1), "sah"
         if walk_order == "near-far":
             sc.set_walk_order(1)
         return sc
@@ -206,6 +233,8 @@ def cpu_baseline(wl, width, height):
     v_all, spp_all, paths_all, dt_all = run(cores, 12.0)
     v_one, spp_one, paths_one, dt_one = run(1, 8.0)
     return {"value": round(v_all, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            # value / (cores x single-thread value): ~1 on a box whose cores are the job's own, far below on a throttled or shared one
+            "parallel_efficiency": round(v_all / (cores * v_one), 3) if v_one > 0 else None,
             "sample": f"{wl['name']} {width}x{height}, {spp_all} spp, depth {DEPTH} ({paths_all} paths in {dt_all:.1f} s on a "
                       f"std::thread pool of {cores} = the cores this job may use (affinity / cgroup quota; os.cpu_count() = {os.cpu_count()}); oracle built -O3)",
             "single_thread": {"value": round(v_one, 4), "cores": 1,
@@ -284,9 +313,15 @@ def roofline_block(workload, st, kernel_ms, pixels, spec_key, spp=None):
     kernel = kernel_name(st)
     pmc = stored_pmc(workload, kernel, spec_key)
     ok = bool(pmc and pmc["matches_this_run"])
+    traffic = pmc.get("hbm_bytes_per_launch") if (ok and spp == pmc.get("spp_of_the_traffic_figure")) else None
+    if traffic is not None and traffic / (kernel_ms * 1e-3) / 1e9 > HBM_PEAK_GBS:
+        traffic = None   # more bytes than the memory can move in the kernel's time: not a usable figure
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": pmc.get("hbm_bytes_per_launch") if (ok and spp == pmc.get("spp_of_the_traffic_figure")) else None,
+            "traffic": traffic,
+            "traffic_is": "TCC<->EA bytes per launch from rocprofv3 counters (FETCH_SIZE x 2 + WRITE_SIZE, separate passes): everything the L2 "
+                          "exchanges with the fabric -- partial sums, scene misses AND the kernels' register-spill scratch, which is most of it "
+                          "on the stack-walk kernels; not ray-state records" if traffic is not None else None,
             "valu_lane_issue_frac": pmc.get("valu_lane_issue_frac") if ok else None,
             "pmc_source": pmc,
             "kernel": kernel, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
@@ -327,17 +362,99 @@ def measure_single(be, dev, key, spp, steps, warmup, bvh, walk_order, generic=Fa
            "value_kernel_only": round(paths / kernel_ms / 1e3, 2),
            "paths_per_step": paths, "segments_per_path": round(st["segments"] / paths, 4),
            "scene_nodes": scene.info()["n_nodes"], "bvh": bvh_label(bvh, walk_order), "dtype": "f64",
-           "roofline": roofline_block(key if (bvh == "reference" and walk_order == "reference") else None, st, kernel_ms, W * H,
+           "roofline": roofline_block(key if (bvh == DEFAULT_BVH and walk_order == "reference") else None, st, kernel_ms, W * H,
                                       spec.get("key") if spec else None, spp)}
     ctx.close()
     return out
 
 
 def bvh_label(bvh, walk_order):
-    tree = ("the reference's build (BVHNode::new, bvh.rs:54-103: random axis, median split; build_seed 1)" if bvh == "reference"
-            else "SAH rebuild of the same leaf sets (rt1w_scene_set_bvh_build; opt-in, statistical parity on entropy-seeded arms)")
+    tree = {"best_axis": "BVHNode::new as written (bvh.rs:54-103: sort by box minimum, median split) with the axis of bvh.rs:84 chosen by the cost of "
+                         "its median split instead of drawn -- a tree the reference's own entropy-seeded build can produce; the library's default",
+            "reference": "BVHNode::new as written with the axis of bvh.rs:84 drawn from build seed 1 (rounds 1-3's default)",
+            "sah": "SAH rebuild of the same leaf sets (rt1w_scene_set_bvh_build; opt-in, statistical parity on entropy-seeded arms)"}[bvh]
     order = "left-then-right (bvh.rs:38-47)" if walk_order == "reference" else "near child first where result-preserving (rt1w_scene_set_walk_order)"
     return f"{tree}; walk order {order}"
+
+
+def tiled_extra(be, dist, rank, world, local_rank, key, W, H, spp, steps, warmup, check_frame, tag):
+    """One of BASELINE's multi-GPU configs as a strong-scaling job of the ranks that are already running: the frame tiled in 16-row
+    strips dealt round-robin, every rank's device->host copy landing in one shared pinned host frame, timed like `value` (barrier +
+    synchronize on both sides, max over ranks).  Returns the entry on rank 0 (None elsewhere)."""
+    import numpy as np
+    import torch
+    rt, sharding = be.rt, be.sharding
+    wl = WORKLOADS[key]
+    scene = be.scene(wl["arm"], W / H, DEFAULT_BVH, "reference")
+    ctx = be.context(scene, local_rank)
+    try:
+        ctx.specialise()
+    except Exception:
+        pass
+    name = f"rt1w_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('RT1W_BENCH_PARENT', os.getppid())}_{tag}"
+    frame = None
+    try:
+        if rank == 0:
+            frame = sharding.SharedFrame(name, W, H, True, rt)
+        dist.barrier()
+        if rank != 0:
+            frame = sharding.SharedFrame(name, W, H, False, rt)
+        host = frame.array
+        y0, rows, srows, period = sharding.interleaved_tile(H, world, rank)
+        kw = dict(max_depth=DEPTH, chunk=rt.default_chunk(W, H, spp))
+
+        def step():
+            return ctx.render(W, H, spp, tile=(0, y0, W, rows), strips=(srows, period), frame=host, **kw)[1] if rows else None
+
+        for _ in range(warmup):
+            step()
+        dist.barrier()
+        be.synchronize()
+        t0 = time.perf_counter()
+        kms, segs = [], 0
+        for _ in range(steps):
+            st = step()
+            if st is not None:
+                kms.append(st["kernel_ms"])
+                segs = st["segments"]
+        dist.barrier()
+        be.synchronize()
+        elapsed = time.perf_counter() - t0
+        mine = {"rank": rank, "rows": rows, "kernel_ms": (sum(kms) / len(kms)) if kms else None, "segments": segs, "elapsed": elapsed}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        elapsed = max(e["elapsed"] for e in every)
+        frame_check = None
+        if check_frame:
+            dist.barrier()
+            be.synchronize()
+            if rank == 0:
+                solo, _ = ctx.render(W, H, spp, **kw)
+                frame_check = bool(np.array_equal(solo, host, equal_nan=True))
+                assert frame_check, f"{tag}: gathered frame differs from the single-GPU frame"
+        if rank != 0:
+            return None
+        paths = W * H * spp
+        per_rank = [e["kernel_ms"] for e in every if e["kernel_ms"] is not None]
+        out = {"workload": f"{wl['name']} (scene arm {wl['arm']}) {W}x{H}, {spp} spp per step, depth {DEPTH}; tiled over {world} ranks "
+                           f"(16-row strips round-robin, one shared pinned host frame, no collective)",
+               "scaling": "strong", "value": round(paths * steps / elapsed / 1e6, 2), "unit": "Mpaths/s (kernels + device->host gather)",
+               "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "paths_per_step": paths,
+               "segments_per_path": round(sum(e["segments"] for e in every) / paths, 4),
+               "n_ranks_seen": sum(1 for e in every if e["rows"] > 0), "rows_per_rank": [e["rows"] for e in every],
+               "kernel_ms_per_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),
+                                      "all": [round(x, 3) for x in per_rank]},
+               "bvh": bvh_label(DEFAULT_BVH, "reference"), "dtype": "f64"}
+        if frame_check is not None:
+            out["gathered_frame_equals_single_gpu_frame"] = frame_check
+        return out
+    finally:
+        ctx.close()
+        if frame is not None:
+            try:
+                dist.barrier()
+            finally:
+                frame.close()
 
 
 def rank_main(a, be=None):
@@ -488,7 +605,7 @@ def rank_main(a, be=None):
                            "host_frame_pin_error": getattr(frame, "pin_error", None) if frame is not None else None,
                            "backend": be.name, "commit": git_head(), "kernel_sources": kernel_sources_id()},
                 "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
-                "roofline": roofline_block(a.workload if (world == 1 and a.bvh == "reference" and a.walk_order == "reference") else None, st, avg_ms,
+                "roofline": roofline_block(a.workload if (world == 1 and a.bvh == DEFAULT_BVH and a.walk_order == "reference") else None, st, avg_ms,
                                            my_pixels, spec.get("key") if spec else None, spp),
             }
             if frame_check is not None:
@@ -498,7 +615,6 @@ def rank_main(a, be=None):
                                          for name, k, s, bvh, order in OTHER_CONFIGS}
             if world == 1 and not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(wl, W, H)
-            print(json.dumps(line), flush=True)
     finally:
         ctx.close()
         if frame is not None:
@@ -507,6 +623,17 @@ def rank_main(a, be=None):
                     dist.barrier()
             finally:
                 frame.close()
+    # N > 1, the default job: BASELINE's two multi-GPU configs on the same ranks (every rank takes part; rank 0 holds the entries)
+    if world > 1 and a.workload == "c3" and not a.no_other_configs and not a.strong and (a.other_size or not (a.width and a.height)):
+        extras = {}
+        for name, key, xspp, xsteps in OTHER_CONFIGS_MULTI:
+            xw, xh = (a.other_size[0], a.other_size[1]) if a.other_size else (WORKLOADS[key]["W"], WORKLOADS[key]["H"])
+            xspp = a.other_size[2] if a.other_size else xspp
+            extras[name] = tiled_extra(be, dist, rank, world, local_rank, key, xw, xh, xspp, xsteps, 1, a.check_frame, name)
+        if rank == 0:
+            line["other_configs"] = extras
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -522,7 +649,8 @@ def parse_args(argv=None):
     ap.add_argument("--generic", action="store_true", help="ablation: the generic kernel instead of the scene-specialised one")
     ap.add_argument("--spp", type=int, default=0, help="default: the workload's own (c3 1000, c2 500, c4 10000, c5 1000)")
     ap.add_argument("--workload", choices=tuple(WORKLOADS), default="c3")
-    ap.add_argument("--bvh", choices=("reference", "sah"), default="reference", help="which tree the big scenes are walked on")
+    ap.add_argument("--bvh", choices=("best_axis", "reference", "sah"), default=DEFAULT_BVH,
+                    help="which tree: best_axis = the library's default (axis chosen), reference = axes drawn from build seed 1, sah = opt-in rebuild")
     ap.add_argument("--walk-order", choices=("reference", "near-far"), default="reference")
     ap.add_argument("--strong", action="store_true", help="N > 1, c3: keep the N = 1 frame (strong scaling of one job)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
@@ -531,6 +659,8 @@ def parse_args(argv=None):
                     help="after timing, rank 0 renders the whole frame alone and requires the gathered frame to be bit-identical")
     ap.add_argument("--width", type=int, default=0, help="tests / rehearsals only: override the frame")
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--other-size", type=int, nargs=3, default=None, metavar=("W", "H", "SPP"),
+                    help="tests / rehearsals only: frame and spp of the N > 1 line's other_configs (c5_strong, c4_strong)")
     return ap.parse_args(argv)
 
 

@@ -52,13 +52,16 @@ class CpuBackend:
         self.sharding = importlib.import_module("raytracing-1w_amd.sharding")
 
     def check_device(self, local_rank):
-        pass
+        # test hook: one rank dies with a message, as a rank without its GPU would
+        if os.environ.get("RT1W_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+            print(f"stdout of the failing rank {os.environ.get('RANK')}", flush=True)
+            raise RuntimeError(f"injected failure of rank {os.environ.get('RANK')}: no device")
 
     def synchronize(self):
         pass
 
     def scene(self, arm, aspect, bvh, walk_order):
-        return self.rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
+        return self.rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect).set_bvh_build(bvh)
 
     def context(self, scene, dev):
         return CpuCtx(self.rt, self.sharding, scene)

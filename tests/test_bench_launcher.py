@@ -44,6 +44,57 @@ def test_bench_three_ranks_with_a_ragged_last_strip(rt):
     assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["gathered_frame_equals_single_gpu_frame"] is True
 
 
+def test_default_multi_rank_line_carries_baselines_multi_gpu_configs(rt):
+    """`python bench.py --gpus N` with no --workload is the one command the driver runs on an 8-GPU node: besides the c3 weak line it
+    must measure BASELINE's two multi-GPU configs -- C5 (4K Cornell) and C4 (final_scene) tiled over the same ranks, strong scaling --
+    as `other_configs` (here at test size, CPU build of the core injected): D2H-inclusive rate, per-rank kernel ms, ranks seen,
+    and the gathered frame equal to the single-rank frame."""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_ranks.py"), "--gpus", "2", "--width", "48", "--height", "48",
+           "--spp", "2", "--steps", "1", "--warmup", "0", "--check-frame", "--no-cpu-baseline", "--other-size", "40", "40", "2"]
+    p = subprocess.run(cmd, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and set(line["other_configs"]) == {"c5_strong", "c4_strong"}
+    for name, arm in (("c5_strong", "scene arm 5"), ("c4_strong", "scene arm 7")):
+        e = line["other_configs"][name]
+        assert arm in e["workload"] and e["scaling"] == "strong" and e["n_ranks_seen"] == 2 and sum(e["rows_per_rank"]) == 40
+        assert e["gathered_frame_equals_single_gpu_frame"] is True
+        assert e["value"] > 0 and e["paths_per_step"] == 40 * 40 * 2 and e["segments_per_path"] > 1.0
+        assert e["kernel_ms_per_rank"]["min"] <= e["kernel_ms_per_rank"]["max"] and len(e["kernel_ms_per_rank"]["all"]) == 2
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt1w_bench_")]
+    # --strong and the explicit workloads are one job each: no extra entries
+    p = subprocess.run(cmd[:-4] + ["--workload", "c2"], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and "other_configs" not in json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+
+
+def test_a_failing_rank_is_heard_and_ends_the_job(rt):
+    """a rank other than 0 that dies (no device, an exception) must end the whole job with a non-zero exit code, and what it printed --
+    stdout included -- must reach the parent's stderr; no JSON line, no shared frame left behind, no hang"""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_ranks.py"), "--gpus", "3", "--width", "32", "--height", "48",
+           "--spp", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-other-configs"]
+    env = dict(_clean_env(), RT1W_TEST_FAIL_RANK="2")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode()
+    assert p.returncode != 0
+    assert "injected failure of rank 2" in err and "stdout of the failing rank 2" in err and "rank 2 exited" in err
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt1w_bench_")]
+
+
+def test_launcher_times_out_instead_of_hanging(rt):
+    sys.path.insert(0, ROOT)
+    import bench
+    script = os.path.join(ROOT, "tests", "_sleep_rank.py")
+    open(script, "w").write("import sys, time\nprint('x' * 200000, flush=True)\ntime.sleep(60)\n")   # > a pipe's buffer on stdout, then stuck
+    try:
+        rc, out0 = bench.launch_ranks(2, [], script=script, timeout=3.0)
+    finally:
+        os.remove(script)
+    assert rc == 124 and len(out0) >= 200000
+
+
 def test_product_bench_fails_loudly_without_a_gpu(rt):
     """the real bench.py has no CPU path: on a box without a GPU every rank dies on the device check and the parent's exit
     code says so (no JSON line)"""
@@ -60,7 +111,7 @@ def test_product_bench_fails_loudly_without_a_gpu(rt):
 def test_launcher_parent_never_touches_the_gpu_stack():
     """the parent process of `--gpus N` must not import torch or load librt1w.so before it forks its ranks"""
     code = ("import sys; sys.argv=['bench.py','--gpus','2']; import bench; "
-            "bench.launch_ranks = lambda n, argv, script=None: (print('MODS', 'torch' in sys.modules, "
+            "bench.launch_ranks = lambda n, argv, script=None, **kw: (print('MODS', 'torch' in sys.modules, "
             "any('raytracing' in m for m in sys.modules)) or (0, '{}\\n')); bench.main()")
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 0, p.stderr.decode()
