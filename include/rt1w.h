@@ -202,6 +202,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_OUT_FRAME 32u /* rt1w_render only: `out_rgb` is the WHOLE image [height][width][3] (row 0 = j = 0) and the call writes just its tile's pixels at their image positions -- several contexts / processes fill one (shared, pinned) host frame: the host gather of the image-tiled multi-GPU job */
 #define RT1W_RNG_REFERENCE 64u /* PARITY MODE: draw from the reference's own generator instead of the Philox streams -- `StdRng::seed_from_u64(j * image_width + i)` (src/main.rs:964; ChaCha12, rand 0.8.4), one stream per pixel drawn on through all its samples in order (sample_offset must be 0, global_seed is ignored).  The frame is then the Rust program's own, pixel for pixel: the GPU reproduces rest_of_your_life.png.  Slower than the default (a lane owns a pixel for all its samples) */
 #define RT1W_CLASSIC_WALK 128u /* tests/ablation: sphere scenes (random_scene) walk their BVH with the pair walk of csrc/rt_walk_pair.h by default (box work and leaf work in separate phases, inner boxes in f32 rounded outward, every sphere gated by its group's own f64 box at the reference's moment: the same frames bit for bit, stats.sorted bit 7 says it ran); this flag keeps the one-entry-per-step walk.  Likewise scenes whose every ConstantMedium is bounded by a bare Sphere (final_scene) run stack-walk kernels built without the general boundary walks (rt_flat.h: RtCfgSphereMedia; stats.sorted bit 8); this flag keeps the general kernels */
+#define RT1W_PROBE_COHERENT 0x40000000u /* MEASUREMENT ONLY -- the frame written is NOT the image: every wave's 64 lanes trace the SAME path (one pixel of every 8x8 block, each 64 times), so the kernel runs without divergence and its instruction count per traced segment (rocprofv3 SQ_INSTS_VALU x 64 / stats.segments) is what ONE path needs in this kernel's code: the `necessary` side of bench.py's `roofline.valu` (tools/bench_pmc.sh).  Replaces nothing of the reference: a property of this implementation's measurement */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering: neither the reordering kernel of the small scenes nor, for sphere-media scenes such as final_scene, the reordering of the finished paths at the end of every slice of the stack walk, stats.sorted bit 9) */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 

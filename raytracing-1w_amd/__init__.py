@@ -34,6 +34,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_STATE, ERR_CANCELLED = 
 ROWS_F64, ROWS_U8 = 0, 1
 OUT_SUM = 1
 UNSORTED = 2
+PROBE_COHERENT = 0x40000000  # measurement only (include/rt1w.h): every wave traces one path 64 times; the frame is not the image
 LDS_NODES = 4
 GENERIC = 8  # do not use a scene-specialised kernel for this render
 OUT_FRAME = 32  # rt1w_render: `out` is the whole image; only the tile's pixels are written, at their image positions
@@ -358,9 +359,9 @@ class Context:
 
     @staticmethod
     def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False,
-                strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False):
+                strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False, probe_coherent=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
-        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (CLASSIC_WALK if classic_walk else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (CLASSIC_WALK if classic_walk else 0) | (PROBE_COHERENT if probe_coherent else 0) | (((variant + 1) << 8) if variant is not None else 0)
         sr, sp = strips if strips is not None else (0, 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp, 1 if f32 else 0, 0)
 
@@ -381,13 +382,14 @@ class Context:
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
                variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False, strips=None, out=None, frame=None,
-               reference_stream=False, f32=False, classic_walk=False):
+               reference_stream=False, f32=False, classic_walk=False, probe_coherent=False):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict).
+        probe_coherent: measurement mode RT1W_PROBE_COHERENT -- the returned array is NOT the image.
         strips=(strip_rows, strip_period): row-interleaved tile (tile row r = image row y0 + r//strip_rows*strip_period +
         r%strip_rows).  out: caller's array for the packed tile (e.g. pinned_empty).  frame: caller's WHOLE image
         [height, width, 3]; the tile's pixels are written at their image positions (RT1W_OUT_FRAME) and `frame` is returned."""
         p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront,
-                         strips, frame is not None, reference_stream, f32, classic_walk)
+                         strips, frame is not None, reference_stream, f32, classic_walk, probe_coherent)
         if frame is not None:
             assert frame.dtype == np.float64 and frame.shape == (height, width, 3) and frame.flags.c_contiguous
             out = frame

@@ -368,6 +368,7 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth;
     f.global_seed = p->global_seed;
     f.strip_rows = p->strip_rows; f.strip_period = p->strip_period;
+    f.probe = (p->flags & RT1W_PROBE_COHERENT) ? 1u : 0u;
     f.chunk = p->chunk ? p->chunk : rt1w_default_chunk(p->tile_w, p->tile_h, p->spp);
     if (f.chunk > f.spp) f.chunk = f.spp;
     f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
@@ -377,7 +378,7 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
         if (p->flags & (RT1W_RNG_REFERENCE | RT1W_WAVEFRONT | RT1W_LDS_NODES)) { rt1w::set_error("RT1W_PRECISION_F32 has the default kernels only"); return RT1W_ERR_INVALID; }
         { const int rcf = ensure_f32_scene(c); if (rcf < 0) return rcf; }
         int v = c->variant == 4 ? 3 : c->variant; /* the order-aware variant exists in f64 only */
-        if (p->flags >> 8) {
+        if ((p->flags >> 8) & 0xFFu) {
             v = (int)((p->flags >> 8) & 0xFFu) - 1;
             if (v == 4 || !rt_variant_valid(v, c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth)) {
                 rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
@@ -385,8 +386,8 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
         }
         /* a context that runs a scene-specialised kernel in f64 uses the f32 build of that kernel too -- from the kernel
          * caches only: renders never compile (rt1w_context_specialise does, for both precisions) */
-        if (!(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !(p->flags >> 8)) (void)specialise_f32(c, false);
-        if (c->jit32_fn && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !(p->flags >> 8)) {
+        if (!(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !((p->flags >> 8) & 0xFFu)) (void)specialise_f32(c, false);
+        if (c->jit32_fn && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED)) && !((p->flags >> 8) & 0xFFu)) {
             L.f32 = true; L.jit = true; L.sorted = true; L.cached = false; L.variant = v; L.grid = c->jit32_grid; L.block = RT_SORT_BLOCK;
             return RT1W_OK;
         }
@@ -418,14 +419,14 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
         return RT1W_OK;
     }
     int variant = c->variant;
-    if (p->flags >> 8) {
+    if ((p->flags >> 8) & 0xFFu) {
         variant = (int)((p->flags >> 8) & 0xFFu) - 1;
         if (!rt_variant_valid(variant, c->n_nodes, c->has_media, c->has_tex, c->has_msphere, c->scope_depth)) {
             rt1w::set_error("forced kernel variant does not cover this scene's features"); return RT1W_ERR_INVALID;
         }
     }
     L.variant = variant;
-    L.jit = c->jit_fn != nullptr && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED | RT1W_LDS_NODES)) && !(p->flags >> 8);
+    L.jit = c->jit_fn != nullptr && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED | RT1W_LDS_NODES)) && !((p->flags >> 8) & 0xFFu);
     if (L.jit) { L.sorted = true; L.cached = false; L.grid = c->jit_grid; L.block = RT_SORT_BLOCK; return RT1W_OK; }
     /* sphere scenes: the pair walk (same frames, bit for bit), unless the caller asks for the one-entry-per-step walk */
     if (c->pw_ok && variant == 5 && !(p->flags & (RT1W_CLASSIC_WALK | RT1W_LDS_NODES | RT1W_WAVEFRONT))) {

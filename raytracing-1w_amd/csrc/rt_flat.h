@@ -144,6 +144,10 @@ struct RtFrame {
     /* row-interleaved tile (image tiling over GPUs: strips of `strip_rows` image rows dealt round-robin): tile row r is
      * image row y0 + (r / strip_rows) * strip_period + r % strip_rows.  strip_rows == 0: contiguous rows y0 + r. */
     uint32_t strip_rows, strip_period;
+    /* MEASUREMENT MODE (RT1W_PROBE_COHERENT; the frame is NOT rendered): the 64 lanes of a wave are given the SAME work item -- one pixel
+     * of every 8x8 block -- so that a wave executes exactly the instructions ONE path needs in this kernel: its VALU instruction count
+     * per traced segment is the necessary work the `roofline.valu` block of bench.py sets the executed work against */
+    uint32_t probe;
 };
 /* image row j (the reference's row index, main.rs:957-964) of tile row py */
 RT_HD uint32_t rt_frame_row(const RtFrame& f, uint32_t py) {

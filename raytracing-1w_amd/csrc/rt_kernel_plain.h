@@ -404,6 +404,10 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
 /* Round 4: the counter is ONE word per slice that every wave adds its newly finished walks to (a relaxed workgroup-scope atomic add by
  * the wave's first walking lane, `ds_add_u32`) and reads back with a relaxed atomic load: the same hint with defined behaviour in the
  * HIP memory model (round 3 had four plain words written by one wave and read by the others with only a compiler fence between). */
+#ifndef RT_SS_ATOMIC_COUNTER
+#define RT_SS_ATOMIC_COUNTER 1 /* 0: round 3's form (A/B only): one plain word per wave, read by the others with a compiler fence in between */
+#endif
+#if RT_SS_ATOMIC_COUNTER
 #define RT_SS_PUBLISH(done_now)                                                                                                   \
     do {                                                                                                                          \
         const uint32_t d_ = (done_now);                                                                                           \
@@ -413,6 +417,10 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
         }                                                                                                                         \
     } while (0)
 #define RT_SS_TOTAL() __hip_atomic_load(&ss_done[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define RT_SS_PUBLISH(done_now) do { if (lane == lead_) ss_done4[parity][wave] = (done_now); asm volatile("" ::: "memory"); } while (0)
+#define RT_SS_TOTAL() (ss_done4[parity][0] + ss_done4[parity][1] + ss_done4[parity][2] + ss_done4[parity][3])
+#endif
 #ifndef RT_SS_WG_SLICE
 #define RT_SS_WG_SLICE 1 /* the slice ends for the whole workgroup at once: every wave publishes how many of its walks have ended and all stop
                             when the workgroup's total reaches 4 x RT_SS_IDLE -- the waves then reach the sort's barrier within a round of each other.
@@ -443,6 +451,10 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
     __shared__ uint32_t ss_done[2];              /* [slice parity]: walks of the workgroup that have ended in this slice */
     uint32_t parity = 0u, ss_pub = 0u;           /* ss_pub: what this wave has added to ss_done[parity] so far (wave-uniform) */
     if (threadIdx.x < 2u) ss_done[threadIdx.x] = 0u;
+#if !RT_SS_ATOMIC_COUNTER
+    __shared__ uint32_t ss_done4[2][4];
+    if (threadIdx.x < 8u) ss_done4[threadIdx.x >> 2][threadIdx.x & 3u] = 0u;
+#endif
     __syncthreads();
     LdsStack stk;
     stk.base = stack_mem + threadIdx.x;
@@ -689,6 +701,9 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         RT_STAMP(9);
         if constexpr (RT_SS_WG_SLICE) { /* the next slice's counter: nobody touches it before the barriers below */
             if (threadIdx.x == 0u) __hip_atomic_store(&ss_done[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if !RT_SS_ATOMIC_COUNTER
+            if (lane == 0u) ss_done4[parity ^ 1u][wave] = 0u;
+#endif
             parity ^= 1u; ss_pub = 0u;
         }
         uint32_t dest = my_rank, idle_total = 0;

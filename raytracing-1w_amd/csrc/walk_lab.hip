@@ -1112,7 +1112,7 @@ int rt1w_lab_dump_rays(rt1w_lab* l, const rt1w_render_params* p, uint32_t n_boun
     RtFrame f; memset(&f, 0, sizeof f);
     f.width = p->width; f.height = p->height; f.x0 = p->x0; f.y0 = p->y0; f.tile_w = p->tile_w; f.tile_h = p->tile_h;
     f.spp = p->spp; f.sample_offset = p->sample_offset; f.max_depth = p->max_depth ? p->max_depth : 50u; f.global_seed = p->global_seed;
-    f.chunk = 1u; f.n_chunks = p->spp; f.strip_rows = 0u; f.strip_period = 0u;
+    f.chunk = 1u; f.n_chunks = p->spp; f.strip_rows = 0u; f.strip_period = 0u; f.probe = 0u;
     const unsigned long long n_paths = (unsigned long long)f.tile_w * f.tile_h * f.spp;
     const size_t bytes = (size_t)n_bounces * n_paths * 8u * sizeof(double);
     double* d_out = nullptr;

@@ -156,7 +156,7 @@ class OracleScene:
 
 class Frame(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
-                                          "max_depth", "global_seed", "chunk", "n_chunks", "strip_rows", "strip_period")]
+                                          "max_depth", "global_seed", "chunk", "n_chunks", "strip_rows", "strip_period", "probe")]
 
 
 B.orcflat_render.restype = C.c_int
