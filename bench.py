@@ -291,6 +291,26 @@ def stored_pmc(workload, kernel, spec_key):
     return ent
 
 
+def valu_block(pmc):
+    """The VALU-side roofline from stored counters (tools/bench_pmc.sh).  `necessary` = VALU instructions ONE path executes per traced
+    segment in this kernel's code, counted by the hardware in the coherent probe (RT1W_PROBE_COHERENT: the 64 lanes of a wave trace the same
+    path, so a wave-instruction is one lane's worth of necessary work): SQ_INSTS_VALU x 64 / segments counted.  `issued` = lane-slots the normal
+    run issues per segment (SQ_INSTS_VALU x 64 / segments), `executed` = those with an active lane (x lanes per instruction).
+    efficiency = necessary / issued: 1.0 would be 64 coherent lanes in every instruction and nothing but the path's own work."""
+    pr = pmc.get("coherent_probe")
+    if not pr or not pr.get("segments_counted") or not pmc.get("segments_counted"):
+        return None
+    necessary = pr["SQ_INSTS_VALU_per_launch"] * 64.0 / pr["segments_counted"]
+    issued = pmc["SQ_INSTS_VALU_per_launch"] * 64.0 / pmc["segments_counted"]
+    executed = issued * pmc["lane_utilisation"]
+    return {"necessary_lane_ops_per_segment": round(necessary, 1), "executed_lane_ops_per_segment": round(executed, 1),
+            "issued_lane_slots_per_segment": round(issued, 1), "efficiency": round(necessary / issued, 4),
+            "necessary_over_executed": round(necessary / executed, 4),
+            "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,   # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz
+            "how": "necessary: rocprofv3 SQ_INSTS_VALU of the RT1W_PROBE_COHERENT run x 64 / its segment count; issued / executed: the same "
+                   "counters of the normal run (profiles/pmc_summary.json)"}
+
+
 def kernel_name(st):
     flags = st.get("sorted", 0)
     if flags & 4:
@@ -323,6 +343,7 @@ def roofline_block(workload, st, kernel_ms, pixels, spec_key, spp=None):
                           "exchanges with the fabric -- partial sums, scene misses AND the kernels' register-spill scratch, which is most of it "
                           "on the stack-walk kernels; not ray-state records" if traffic is not None else None,
             "valu_lane_issue_frac": pmc.get("valu_lane_issue_frac") if ok else None,
+            "valu": valu_block(pmc) if ok else None,
             "pmc_source": pmc,
             "kernel": kernel, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
             "true_limiter": "f64 VALU issue + lane divergence (valu_lane_issue_frac): the ray state stays in VGPRs, so measured HBM "
@@ -525,6 +546,8 @@ def rank_main(a, be=None):
     y0, rows, srows, period = sharding.interleaved_tile(H, world, rank)
     chunk = rt.default_chunk(W, H, spp)                                  # the whole frame's chunking: same sums as one GPU
     kw = dict(max_depth=DEPTH, generic=a.generic, chunk=chunk)
+    if a.probe_coherent:
+        kw["probe_coherent"] = True
     tile = (0, y0, W, rows)
 
     def step():
@@ -603,7 +626,8 @@ def rank_main(a, be=None):
                                           else "1 GPU, D2H into a pinned host frame",
                            "host_frame_pinned": bool(frame._pinned) if frame is not None else True,
                            "host_frame_pin_error": getattr(frame, "pin_error", None) if frame is not None else None,
-                           "backend": be.name, "commit": git_head(), "kernel_sources": kernel_sources_id()},
+                           "backend": be.name, "commit": git_head(), "kernel_sources": kernel_sources_id(),
+                           "probe_coherent": bool(a.probe_coherent), "segments_counted": seg_total},
                 "value_device_resident": round(my_pixels * spp / (dev_ms * 1e-3) / 1e6 * (world if world > 1 else 1), 2) if dev_ms else None,
                 "roofline": roofline_block(a.workload if (world == 1 and a.bvh == DEFAULT_BVH and a.walk_order == "reference") else None, st, avg_ms,
                                            my_pixels, spec.get("key") if spec else None, spp),
@@ -659,6 +683,8 @@ def parse_args(argv=None):
                     help="after timing, rank 0 renders the whole frame alone and requires the gathered frame to be bit-identical")
     ap.add_argument("--width", type=int, default=0, help="tests / rehearsals only: override the frame")
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--probe-coherent", action="store_true",
+                    help="measurement runs under rocprofv3 only (tools/bench_pmc.sh): RT1W_PROBE_COHERENT, every wave traces one path 64 times; `value` is then meaningless")
     ap.add_argument("--other-size", type=int, nargs=3, default=None, metavar=("W", "H", "SPP"),
                     help="tests / rehearsals only: frame and spp of the N > 1 line's other_configs (c5_strong, c4_strong)")
     return ap.parse_args(argv)

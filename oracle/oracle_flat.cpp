@@ -17,6 +17,9 @@
 #include <cstring>
 
 #include "rt_core.h"
+#if !defined(RT_RNG_REFSTREAM)
+#include "rt_walk_pair.h" /* the pair walk of sphere scenes: its lane functions are built here with bound-checked stacks and queues */
+#endif
 
 /* tests/test_static_sweep.py compiles this file a second time with a generated header that defines scene topologies
  * as compile-time arrays (what the library's run-time compiler does for the GPU, jit.cpp) and adds them as variants
@@ -167,3 +170,88 @@ void orcflat_rng_rewind_check(uint64_t seed, uint32_t pattern, uint32_t before, 
 }
 
 } /* extern "C" */
+
+#if !defined(RT_RNG_REFSTREAM)
+namespace {
+/* an array the pair walk's lane functions index like their LDS columns, bounds checked: a write or read outside is recorded, not done */
+template <class T>
+struct Checked {
+    std::vector<T> v;
+    bool* fault;
+    T dummy{};
+    T& operator[](long i) {
+        if (i < 0 || (size_t)i >= v.size()) { *fault = true; return dummy; }
+        return v[(size_t)i];
+    }
+};
+}
+/* The pair walk (rt_walk_pair.h) on the CPU, ray by ray, against the one-entry-per-step walk.  `rays[n][8]` = origin, direction, time, unused.
+ * Each ray is walked as ONE lane would be by rt_render_ss_body / rt_render_plain_body -- the root's box, then box work and leaf work,
+ * the NaN hand-overs (a NaN shutter fraction; a closest hit that turns NaN) -- under a RANDOM schedule (seeded): whether the lane does
+ * box work or leaf work next, and how many inner records it takes on a box vote, is drawn; the exactness argument says the result may
+ * not depend on it.  Stack (`stack_cap` entries) and queue (RT_PW_QCAP) are bound-checked.  out_flags per ray: bit 0 the segment was
+ * handed to the classic walk, bit 1 an index left its array (a defect), bit 2 the ray missed the root box.  Returns 0, or -1 when the
+ * scene is outside the pair walk's scope. */
+extern "C" int orcflat_pair_walk(const void* nodes_, uint32_t n_nodes, uint32_t root, const double* rays, uint64_t n, uint32_t stack_cap,
+                                 uint64_t schedule_seed, double* out_t, uint32_t* out_prim, double* ref_t, uint32_t* ref_prim, uint32_t* out_flags) {
+    const RtNode* nodes = (const RtNode*)nodes_;
+    std::vector<RtNode> N(nodes, nodes + n_nodes);
+    std::vector<RtPwInner> inner;
+    std::vector<RtPwGroup> groups;
+    RtPwView pw;
+    std::string why;
+    if (!rt_pw_build(N, root, inner, groups, pw, why)) return -1;
+    pw.inner = inner.data(); pw.groups = groups.data();
+    RtSceneView sc;
+    std::memset(&sc, 0, sizeof sc);
+    sc.nodes = nodes; sc.root = root; sc.n_nodes = n_nodes;
+    RtGlobalNodes ns{nodes};
+    uint64_t lcg = schedule_seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto draw = [&lcg]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(lcg >> 33); };
+    for (uint64_t i = 0; i < n; ++i) {
+        RtRay ray;
+        ray.o = rt_v3(rays[i * 8], rays[i * 8 + 1], rays[i * 8 + 2]);
+        ray.d = rt_v3(rays[i * 8 + 3], rays[i * 8 + 4], rays[i * 8 + 5]);
+        ray.time = rays[i * 8 + 6];
+        RtRng rng = rt_rng_pixel_sample(i, 0u, 0u); /* such a scene's walk draws nothing */
+        uint32_t scope_;
+        {   /* the reference answer: the one-entry-per-step walk */
+            HostStack cs;
+            double t = RT_INF; uint32_t prim = RT_NONE;
+            rt_traverse_stack<RtCfgV5, true>(sc, ns, root, ray, RT_R(0.001), RT_INF, rng, cs, t, prim, scope_);
+            ref_t[i] = t; ref_prim[i] = prim;
+        }
+        bool fault = false;
+        RtPwLds<1, Checked<uint32_t>, Checked<float>, Checked<uint32_t>> m{{std::vector<uint32_t>(stack_cap), &fault}, {std::vector<float>(stack_cap), &fault},
+                                                                             {std::vector<uint32_t>(RT_PW_QCAP), &fault}};
+        RtPwLane L; L.cur = RT_PW_NONE; L.qh = 0u; L.qn = 0u; L.sp = 0;
+        uint32_t flags = 0u;
+        double best_t = RT_INF; uint32_t best_prim = RT_NONE;
+        const double frac0 = (ray.time - pw.ms_time0) / (pw.ms_time1 - pw.ms_time0);
+        bool bad = rt_isnan(frac0), walking = bad;
+        const RtV3 inv = rt_inv3(ray.d);
+        if (!bad) walking = rt_pw_begin(pw, L, m, ray.o, inv, RT_R(0.001));
+        if (!walking) flags |= 4u;
+        while (walking && !bad && !rt_pw_done(L) && !fault) {
+            const bool can_box = rt_pw_can_box(L), can_leaf = L.qn > 0u;
+            if (can_leaf && (!can_box || (draw() & 1u))) {
+                rt_pw_group_step(pw, L, m, ray.o, ray.d, inv, frac0, RT_R(0.001), best_t, best_prim);
+                if (rt_isnan(best_t)) bad = true;
+            } else if (can_box) {
+                const uint32_t steps = 1u + draw() % 6u;
+                for (uint32_t k = 0; k < steps && rt_pw_can_box(L); ++k) rt_pw_box_step(pw, L, m, ray.o, inv, RT_R(0.001), best_t);
+            } else { fault = true; } /* neither kind of work and not done: the state machine is stuck */
+        }
+        if (bad) { /* the hand-over of the kernels: the segment is redone by the one-entry-per-step walk */
+            HostStack cs;
+            best_t = RT_INF; best_prim = RT_NONE;
+            rt_traverse_stack<RtCfgV5, true>(sc, ns, root, ray, RT_R(0.001), RT_INF, rng, cs, best_t, best_prim, scope_);
+            flags |= 1u;
+        }
+        if (fault) flags |= 2u;
+        out_t[i] = best_t; out_prim[i] = best_prim; out_flags[i] = flags;
+    }
+    return 0;
+}
+#endif
+

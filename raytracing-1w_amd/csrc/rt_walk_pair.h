@@ -19,6 +19,9 @@
 #define RT1W_WALK_PAIR_H
 
 #include "rt_core.h"
+#if !defined(__HIPCC__)
+#include <cmath>
+#endif
 
 #define RT_PW_LEAF 0x80000000u
 #define RT_PW_NONE 0xFFFFFFFFu
@@ -52,20 +55,29 @@ struct RtPwView {
     double ms_time0, ms_time1; /* the scene's one shutter interval (main.rs:230-237: every moving sphere has (0, 1)) */
 };
 
+/* The lane functions below are plain C++ apart from the directed rounding: the CPU test build (oracle/oracle_flat.cpp) compiles the
+ * same text with bound-checked stacks and queues (RtPwLds::ref / ent / q may be any type with operator[]) and a randomised schedule. */
 #if defined(__HIPCC__)
+#define RT_PW_FN __device__ __forceinline__
+#define RT_PW_ROUND_DOWN(x) __double2float_rd(x)
+#else
+#define RT_PW_FN inline
+static inline float rt_pw_round_down_host(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
+#define RT_PW_ROUND_DOWN(x) rt_pw_round_down_host(x)
+#endif
 /* per-lane walk state that lives across the slices of a walk: the next inner record, the stack level, the queue window (the
  * stack and the queue themselves are in LDS) */
 struct RtPwLane {
     uint32_t cur, qh, qn;
     int sp;
 };
-template <int BLOCK>
+template <int BLOCK, class RefT = uint32_t*, class EntT = float*, class QT = uint32_t*>
 struct RtPwLds {
-    uint32_t* ref; /* [RT_PW_STACK][BLOCK] */
-    float* ent;    /* entry distance of the pushed box, rounded DOWN (culling at the pop may miss, never over-cull) */
-    uint32_t* q;   /* [RT_PW_QCAP][BLOCK] */
+    RefT ref; /* [RT_PW_STACK][BLOCK] */
+    EntT ent; /* entry distance of the pushed box, rounded DOWN (culling at the pop may miss, never over-cull) */
+    QT q;     /* [RT_PW_QCAP][BLOCK] */
 };
-__device__ __forceinline__ void rt_pw_slab(const float* bb, RtV3 o, RtV3 inv, double t_min, double& enter, double& exit_) {
+RT_PW_FN void rt_pw_slab(const float* bb, RtV3 o, RtV3 inv, double t_min, double& enter, double& exit_) {
     /* aabb.rs:14-29 with the interval kept by max/min (rt_aabb_hit_fast's arithmetic), t_max not folded in */
     double lo = t_min, hi = RT_INF;
 #define RT_PW_AX(minv, maxv, ov, iv)                     \
@@ -83,20 +95,20 @@ __device__ __forceinline__ void rt_pw_slab(const float* bb, RtV3 o, RtV3 inv, do
     enter = lo; exit_ = hi;
 }
 /* the root's own box, exactly as the reference tests it first (bvh.rs:32); false: the ray misses the scene */
-template <int BLOCK>
-__device__ __forceinline__ bool rt_pw_begin(const RtPwView& pw, RtPwLane& L, const RtPwLds<BLOCK>& m, RtV3 o, RtV3 inv, double t_min) {
+template <int BLOCK, class RefT, class EntT, class QT>
+RT_PW_FN bool rt_pw_begin(const RtPwView& pw, RtPwLane& L, RtPwLds<BLOCK, RefT, EntT, QT>& m, RtV3 o, RtV3 inv, double t_min) {
     L.sp = 0; L.qh = 0u; L.qn = 0u; L.cur = RT_PW_NONE;
     if (!rt_aabb_hit_fast<false>(pw.root_box, o, inv, t_min, RT_INF)) return false;
     if (pw.root & RT_PW_LEAF) { m.q[0] = pw.root & ~RT_PW_LEAF; L.qn = 1u; }
     else L.cur = pw.root;
     return true;
 }
-__device__ __forceinline__ bool rt_pw_done(const RtPwLane& L) { return L.cur == RT_PW_NONE && L.sp == 0 && L.qn == 0u; }
-__device__ __forceinline__ bool rt_pw_can_box(const RtPwLane& L) { return (L.cur != RT_PW_NONE || L.sp > 0) && L.qn + 2u <= (uint32_t)RT_PW_QCAP; }
+RT_PW_FN bool rt_pw_done(const RtPwLane& L) { return L.cur == RT_PW_NONE && L.sp == 0 && L.qn == 0u; }
+RT_PW_FN bool rt_pw_can_box(const RtPwLane& L) { return (L.cur != RT_PW_NONE || L.sp > 0) && L.qn + 2u <= (uint32_t)RT_PW_QCAP; }
 
 /* BOX WORK of one lane: back to the nearest pushed right child if there is no current record, then one inner record */
-template <int BLOCK>
-__device__ __forceinline__ void rt_pw_box_step(const RtPwView& pw, RtPwLane& L, const RtPwLds<BLOCK>& m, RtV3 o, RtV3 inv, double t_min, double best_t) {
+template <int BLOCK, class RefT, class EntT, class QT>
+RT_PW_FN void rt_pw_box_step(const RtPwView& pw, RtPwLane& L, RtPwLds<BLOCK, RefT, EntT, QT>& m, RtV3 o, RtV3 inv, double t_min, double best_t) {
     if (L.cur == RT_PW_NONE) {
         --L.sp;
         const uint32_t ref = m.ref[L.sp * BLOCK];
@@ -121,7 +133,7 @@ __device__ __forceinline__ void rt_pw_box_step(const RtPwView& pw, RtPwLane& L, 
         if (pr) {
             if (left_entered) { /* after the left subtree: bvh.rs:38-47 */
                 m.ref[L.sp * BLOCK] = P.r;
-                m.ent[L.sp * BLOCK] = __double2float_rd(er);
+                m.ent[L.sp * BLOCK] = RT_PW_ROUND_DOWN(er);
                 ++L.sp;
             } else if (P.r & RT_PW_LEAF) { m.q[((L.qh + L.qn) & (RT_PW_QCAP - 1u)) * BLOCK] = P.r & ~RT_PW_LEAF; L.qn += 1u; }
             else next = P.r;
@@ -131,8 +143,8 @@ __device__ __forceinline__ void rt_pw_box_step(const RtPwView& pw, RtPwLane& L, 
 }
 /* LEAF WORK of one lane: its oldest pending group -- the reference's BVHNode::hit on that node: its box with the closest hit as
  * it is NOW, then its one or two spheres, left first.  `frac` = (time - time0) / (time1 - time0) of MovingSphere::center */
-template <int BLOCK>
-__device__ __forceinline__ void rt_pw_group_step(const RtPwView& pw, RtPwLane& L, const RtPwLds<BLOCK>& m, RtV3 o, RtV3 d, RtV3 inv, double frac, double t_min,
+template <int BLOCK, class RefT, class EntT, class QT>
+RT_PW_FN void rt_pw_group_step(const RtPwView& pw, RtPwLane& L, RtPwLds<BLOCK, RefT, EntT, QT>& m, RtV3 o, RtV3 d, RtV3 inv, double frac, double t_min,
                                                  double& best_t, uint32_t& best_prim) {
     const uint32_t g = m.q[(L.qh & (RT_PW_QCAP - 1u)) * BLOCK];
     L.qh += 1u; L.qn -= 1u;
@@ -150,7 +162,6 @@ __device__ __forceinline__ void rt_pw_group_step(const RtPwView& pw, RtPwLane& L
         }
     }
 }
-#endif /* __HIPCC__ */
 
 #if !defined(RT_PW_DEVICE_ONLY)
 #include <cmath>

@@ -27,6 +27,13 @@ SCRIPT = textwrap.dedent("""
             img, st = orc.flat_render(sc, W, H, spp, variant=v, threads=1)
             ref = img if ref is None else ref
             assert np.array_equal(img, ref, equal_nan=True)
+    # the pair walk's lane functions (rt_walk_pair.h) with their bound-checked host arrays, finite and non-finite rays
+    import test_pair_walk_host as pw
+    rng = np.random.default_rng(3)
+    sc0 = rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5)
+    for rays in (pw.rays_for(1, 1500, rng), pw.nasty(pw.rays_for(1, 1500, rng), rng)):
+        t, prim, rt_, rprim, flags = pw.pair_walk(B, sc0, rays, stack_cap=12, seed=5)
+        assert not (flags & 2).any() and np.array_equal(prim, rprim)
     print('SANITIZED-OK')
 """)
 

@@ -15,6 +15,8 @@ for wl in c3 c2 c4; do
     i=$((i+1))
     (cd $GRAFT_REPO_ROOT && timeout -k 10 200 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/$wl/p$i -- python3 bench.py $ARGS --steps 2 --warmup 0 --no-cpu-baseline --no-other-configs > $OUT/$wl.p$i.log 2>&1) || echo "$wl pass $i failed"
   done
+  # the coherent probe (RT1W_PROBE_COHERENT: every wave traces one path 64 times): the necessary VALU instructions per segment
+  (cd $GRAFT_REPO_ROOT && timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/$wl/probe -- python3 bench.py $ARGS --probe-coherent --steps 2 --warmup 0 --no-cpu-baseline --no-other-configs > $OUT/$wl.probe.log 2>&1) || echo "$wl probe pass failed"
 done
 export OUT
 python3 - <<'PY'
@@ -24,7 +26,20 @@ out = {}
 for wl, spp in (("c3", 1000), ("c2", 500), ("c4", 400)):
     agg = collections.defaultdict(list)
     names = collections.Counter()
-    for f in sorted(glob.glob(OUT + "/%s/p*/**/*counter_collection.csv" % wl, recursive=True)):
+    probe = collections.defaultdict(list)
+    for f in sorted(glob.glob(OUT + "/%s/probe/**/*counter_collection.csv" % wl, recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if "rt_jit_sorted" in r["Kernel_Name"] or "rt_render_kernel" in r["Kernel_Name"]:
+                probe[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    pm = {k: sum(v) / len(v) for k, v in probe.items()}
+    pline = {}
+    try:
+        for l in open(OUT + "/%s.probe.log" % wl):
+            if l.startswith("{"):
+                pline = json.loads(l)
+    except OSError:
+        pass
+    for f in sorted(glob.glob(OUT + "/%s/p[0-9]*/**/*counter_collection.csv" % wl, recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "rt_jit_sorted" in k or "rt_render_kernel" in k:
@@ -44,6 +59,11 @@ for wl, spp in (("c3", 1000), ("c2", 500), ("c4", 400)):
     out[wl] = {"kernel": kern, "specialise_key": (line.get("config", {}).get("specialise") or {}).get("key") if kern == "rt_jit_sorted" else None,
                "spp_of_the_traffic_figure": spp, "commit": line.get("config", {}).get("commit"),
                "kernel_sources": line.get("config", {}).get("kernel_sources"),
+               "segments_counted": line.get("config", {}).get("segments_counted"),
+               "coherent_probe": ({"SQ_INSTS_VALU_per_launch": pm["SQ_INSTS_VALU"], "SQ_INSTS_SALU_per_launch": pm.get("SQ_INSTS_SALU"),
+                                   "lane_utilisation": round(pm["SQ_THREAD_CYCLES_VALU"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]), 4) if pm.get("SQ_ACTIVE_INST_VALU") else None,
+                                   "segments_counted": pline.get("config", {}).get("segments_counted"), "kernel": pline.get("roofline", {}).get("kernel")}
+                                  if pm.get("SQ_INSTS_VALU") else None),
                "valu_busy_frac": round(busy, 4), "lane_utilisation": round(lanes, 4), "valu_lane_issue_frac": round(busy * lanes, 4),
                "wave_cycles_waiting_frac": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 4),
                "SQ_INSTS_VALU_per_launch": m["SQ_INSTS_VALU"], "SQ_INSTS_SALU_per_launch": m["SQ_INSTS_SALU"],
