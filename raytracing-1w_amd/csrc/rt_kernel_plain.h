@@ -254,6 +254,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 }
             }
             if (!walking) {
+                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0)); /* written by the terminal only: not carried across the walk */
                 rt_path_shade<Cfg>(sc, path, tr);
                 if (!path.alive) {
                     sum = rt_v3d_add(sum, path.radiance);
@@ -346,6 +347,7 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
                 }
             }
             if (!walking) {
+                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0)); /* written by the terminal only: not carried across the walk */
                 rt_path_shade<Cfg>(sc, path, tr);
                 if (!path.alive) {
                     sum = rt_v3d_add(sum, path.radiance);

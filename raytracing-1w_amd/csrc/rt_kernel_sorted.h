@@ -252,10 +252,12 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
         RT_STAMP(7);
         /* 4. shading (coherent within a wave after the sort) */
         if (!retired) {
+            /* a path's radiance is written by its terminal only (rt_path_shade: the emitting material never scatters), so it is zero here
+             * and nothing of it is carried across the loop or through the exchange */
+            path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
             rt_path_shade<Cfg>(sc, path, tr);
             if (!path.alive) {
                 sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
-                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
                 ++s;
             }
         }
