@@ -193,7 +193,7 @@ struct rt1w_context {
     WfRecs wf_recs = {nullptr, 0.0, 1.0}; void* d_wf_recs = nullptr; /* walk records of the big scenes (null: not eligible) */
     int wf_grid_trace[22] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
     uint32_t stack_need = 0;
-    int ref_grid[2] = {0, 0}; /* reference-stream kernels: sweep, stack walk */
+    int ref_grid[4] = {0, 0, 0, 0}; /* reference-stream kernels: sweep, stack walk, reordering V0, reordering every-feature */
     void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays, built at the first f32 render */
     bool f32_tried = false, wf_recs_tried = false; std::string wf_recs_error;
     /* pair walk (rt_walk_pair.h): records of an eligible scene (sphere-only, variant 5), the kernel's grid */
@@ -409,13 +409,15 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
         if (p->sample_offset != 0u) { rt1w::set_error("RT1W_RNG_REFERENCE: one stream per pixel, sample_offset must be 0"); return RT1W_ERR_INVALID; }
         f.chunk = f.spp; f.n_chunks = 1u; f.global_seed = 0u;
         const bool stack_walk = c->n_nodes > RT_SWEEP_MAX_NODES;
-        if (!c->ref_grid[stack_walk]) {
+        /* small scenes: through the workgroup-level path reordering (the stream's state travels with the path) unless RT1W_UNSORTED */
+        const int mode = stack_walk ? 1 : ((p->flags & RT1W_UNSORTED) ? 0 : (c->variant == 0 ? 2 : 3));
+        if (!c->ref_grid[mode]) {
             hipDeviceProp_t prop;
             if (!hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
-            c->ref_grid[stack_walk] = prop.multiProcessorCount * rt1w_internal_ref_blocks_per_cu(stack_walk ? 1 : 0);
+            c->ref_grid[mode] = prop.multiProcessorCount * rt1w_internal_ref_blocks_per_cu(mode);
         }
-        L.ref = true; L.jit = false; L.sorted = false; L.cached = false;
-        L.variant = stack_walk ? 3 : 1; L.grid = c->ref_grid[stack_walk]; L.block = RT_BLOCK;
+        L.ref = true; L.jit = false; L.sorted = mode >= 2; L.cached = false;
+        L.variant = stack_walk ? 3 : (mode == 2 ? 0 : 1); L.grid = c->ref_grid[mode]; L.block = mode >= 2 ? RT_SORT_BLOCK : RT_BLOCK;
         return RT1W_OK;
     }
     int variant = c->variant;
@@ -473,7 +475,7 @@ int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const
         }
     } else if (L.ref) {
         if (rt1w_internal_ref_sizeof(0) != sizeof(RtSceneView) || rt1w_internal_ref_sizeof(1) != sizeof(RtFrame) ||
-            rt1w_internal_ref_launch(L.variant == 3 ? 1 : 0, &c->view, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
+            rt1w_internal_ref_launch(L.variant == 3 ? 1 : (L.sorted ? (L.variant == 0 ? 2 : 3) : 0), &c->view, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
             rt1w::set_error("reference-stream kernel launch failed"); return RT1W_ERR_DEVICE;
         }
     } else if (L.jit) {

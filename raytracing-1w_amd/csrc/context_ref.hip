@@ -11,7 +11,10 @@
  * With it the GPU reproduces the reference's own render, rest_of_your_life.png (600x600, 100 spp), pixel for pixel
  * (tests/test_gpu_parity.py::test_gpu_reference_stream_reproduces_the_reference_png): the elementary functions here are
  * the numerical contract's, not libm's, but an ulp only matters when it flips a branch (~1e-13 per decision).
- * A parity mode, not a fast path: one lane owns a pixel for all its samples, the ChaCha block is recomputed per four words.
+ * A parity mode: a path slot owns a pixel for all its samples (chunk = spp) and the ChaCha block is recomputed per four words.
+ * Round 4: small scenes run it through the workgroup-level path reordering too (rt_render_sorted_body: the generator state is part of
+ * the exchanged path state, so a pixel's stream moves with its path from lane to lane) -- the same frame, bit for bit, as the plain
+ * kernel (RT1W_UNSORTED), at about three times its rate where there are enough pixels to fill the GPU.
  */
 #include <hip/hip_runtime.h>
 
@@ -35,11 +38,24 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void rt_render_kernel_ref(RtSceneView 
                                                                    unsigned long long* __restrict__ counters) {
     rt_render_plain_body<Cfg, false>(sc, f, partial, counters);
 }
+/* the reordering kernel (rt_kernel_sorted.h) on the reference's stream: RtCfgV0 for scenes of solid colours without media or moving
+ * spheres (Cornell: what the reference's own PNG shows), the every-feature sweep otherwise */
+template <class Cfg>
+__global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_ref_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+                                                                                           unsigned long long* __restrict__ counters) {
+    rt_render_sorted_body<Cfg>(sc, f, partial, counters);
+}
 } // namespace rtref
 
 /* called by context.hip; `view` / `frame` are the bytes of its RtSceneView / RtFrame (same layout: same headers) */
+/* mode: 0 sweep (plain kernel), 1 stack walk (plain kernel), 2 reordering kernel V0, 3 reordering kernel with every feature */
 extern "C" int rt1w_internal_ref_blocks_per_cu(int stack_walk) {
     int per_cu = 0;
+    if (stack_walk >= 2) {
+        hipError_t e2 = stack_walk == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtref::rt_render_kernel_ref_sorted<rtref::RtCfgV0>, RT_SORT_BLOCK, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtref::rt_render_kernel_ref_sorted<rtref::CfgSweep>, RT_SORT_BLOCK, 0);
+        return e2 == hipSuccess && per_cu > 0 ? per_cu : 1;
+    }
     hipError_t e = stack_walk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtref::rt_render_kernel_ref<rtref::CfgStack>, RT_BLOCK, 0)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtref::rt_render_kernel_ref<rtref::CfgSweep>, RT_BLOCK, 0);
     return e == hipSuccess && per_cu > 0 ? per_cu : 1;
@@ -50,7 +66,9 @@ extern "C" int rt1w_internal_ref_launch(int stack_walk, const void* view, const 
     rtref::RtFrame f;
     memcpy(&v, view, sizeof v);
     memcpy(&f, frame, sizeof f);
-    if (stack_walk) hipLaunchKernelGGL(rtref::rt_render_kernel_ref<rtref::CfgStack>, dim3(grid), dim3(RT_BLOCK), 0, stream, v, f, partial, counters);
+    if (stack_walk == 2) hipLaunchKernelGGL(rtref::rt_render_kernel_ref_sorted<rtref::RtCfgV0>, dim3(grid), dim3(RT_SORT_BLOCK), 0, stream, v, f, partial, counters);
+    else if (stack_walk == 3) hipLaunchKernelGGL(rtref::rt_render_kernel_ref_sorted<rtref::CfgSweep>, dim3(grid), dim3(RT_SORT_BLOCK), 0, stream, v, f, partial, counters);
+    else if (stack_walk) hipLaunchKernelGGL(rtref::rt_render_kernel_ref<rtref::CfgStack>, dim3(grid), dim3(RT_BLOCK), 0, stream, v, f, partial, counters);
     else hipLaunchKernelGGL(rtref::rt_render_kernel_ref<rtref::CfgSweep>, dim3(grid), dim3(RT_BLOCK), 0, stream, v, f, partial, counters);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

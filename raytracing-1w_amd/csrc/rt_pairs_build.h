@@ -1,4 +1,4 @@
-/* rt_pairs_build.h -- host side of the stack walk with pair records (rt_core.h: RtPairRec, rt_walkp_step): which BVH nodes only
+/* rt_pairs_build.h -- host side of the stack walk with pair records (rt_walk_w3.h: RtPairRec, rt_walkp_step): which BVH nodes only
  * steer, their records, and the node array patched for that walk.  Per context; the scene's own flat arrays are not touched. */
 #ifndef RT1W_PAIRS_BUILD_H
 #define RT1W_PAIRS_BUILD_H
@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include "rt_core.h"
+#include "rt_walk_w3.h"
 
 struct RtPairsInfo {
     uint32_t n_bvh = 0, n_steer = 0, n_not_inside = 0;

@@ -17,7 +17,7 @@
  *   mode 7  W0b: W0 with four box-only steps behind every full step (rt_walk_box_step): a lane between boxes advances several nodes
  *           per execution of the rare kinds' code.  In the product for scenes with media (rt_kernel_plain.h: RT_SLICE_BOX_STEPS).
  *   mode 10 W0c: W0b with the top of the stack in a register during the box-only steps (rt_kernel_sorted.h: rt_walk_box_run).
- *   mode 8  W3: W0b with pair records for the BVH nodes that only steer (rt_core.h: rt_walkp_step): a steering node's record holds
+ *   mode 8  W3: W0b with pair records for the BVH nodes that only steer (rt_walk_w3.h: rt_walkp_step): a steering node's record holds
  *           both children's boxes in f32 rounded outward; a child whose box fails is never popped or fetched; gates (BVH nodes
  *           directly above a primitive, a wrapper or a medium) keep their exact f64 test.  mode 9: the same without box-only steps.
  *   mode 3  W0q: W0 with the node records fetched by quads (four lanes share each 64-byte access) and transposed with DPP.
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w4(RtSceneView sc, cons
 
 /* ------------------------------------------------------------------------------------------------- W3 -- */
 
-/* W3: the one-entry-per-step walk with PAIR RECORDS for the BVH nodes that only steer (rt_core.h: rt_walkp_step; `sc.nodes` is the
+/* W3: the one-entry-per-step walk with PAIR RECORDS for the BVH nodes that only steer (rt_walk_w3.h: rt_walkp_step; `sc.nodes` is the
  * patched copy, rt_pairs_build.h) and BOXSTEPS box-only steps behind every full step */
 template <class Cfg, int BOXSTEPS>
 __global__ __launch_bounds__(RT_BLOCK, 3) void lab_trace_w3(RtSceneView sc, const RtPairRec* __restrict__ pairs, const LabRay* __restrict__ rays, unsigned long long n,

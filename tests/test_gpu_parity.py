@@ -623,6 +623,7 @@ def test_gpu_reference_stream_reproduces_the_reference_png(rt, gpu_ctx_factory):
     ctx = gpu_ctx_factory(sc)
     u8, st = ctx.render_u8(600, 600, 100, reference_stream=True)
     assert st["sorted"] & 16 and st["n_chunks"] == 1
+    assert st["sorted"] & 1, "the reference stream did not go through the reordering kernel"   # round 4: the generator state travels with the path
     bad = [r for r in range(600) if zlib.crc32(np.ascontiguousarray(u8[r]).tobytes()) != pix["row_crc32_top_down"][r]]
     assert not bad, f"{len(bad)} rows differ from the reference PNG, first: {bad[:5]}"
     assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).hexdigest() == pix["sha256_rgb_top_down"]
@@ -633,6 +634,10 @@ def test_gpu_reference_stream_reproduces_the_reference_png(rt, gpu_ctx_factory):
     assert np.array_equal(again, u8)
     philox, _ = ctx.render_u8(600, 600, 100)
     assert (philox != u8).any()
+    full, sf = ctx.render(600, 600, 100, reference_stream=True)
+    plain, sp = ctx.render(600, 600, 100, reference_stream=True, unsorted=True)      # one lane per pixel for all samples: round 2's form
+    assert (sf["sorted"] & 17) == 17 and sp["sorted"] & 16 and not (sp["sorted"] & 1)
+    assert sp["segments"] == sf["segments"] == st["segments"] and np.array_equal(plain, full)
     with pytest.raises(rt.Rt1wError):
         ctx.render(64, 64, 4, sample_offset=2, reference_stream=True)
     # a big scene goes through the stack-walk build of the same kernel: equal to the CPU build of the core

@@ -1,4 +1,4 @@
-// tools/pairs_check.cpp -- the stack walk with pair records (rt_core.h: rt_walkp_step) against the one-entry-per-step walk on the CPU:
+// tools/pairs_check.cpp -- the stack walk with pair records (rt_walk_w3.h: rt_walkp_step) against the one-entry-per-step walk on the CPU:
 // every segment of every path walked both ways (t, primitive, scope and the generator state compared), steps per segment by kind.
 // Measurement / debugging tool, not product.  Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Iraytracing-1w_amd/csrc
 // tools/pairs_check.cpp -o /tmp/pairs_check -Lraytracing-1w_amd -lrt1w -Wl,-rpath,$PWD/raytracing-1w_amd ; /tmp/pairs_check <arm> <W> <H> <spp> [sah]
