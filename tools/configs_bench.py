@@ -34,6 +34,11 @@ for name, arm, aspect, W, H, spp in (("C2 random_scene", 0, 1.5, 1200, 800, 100)
     line = (f"{name:18s} {W}x{H} nodes {sc.info()['n_nodes']:5d} seg/path {st['segments'] / st['paths']:.2f} | default V{st['variant']} {kind} "
             f"{best:7.1f}")
     if st["variant"] >= 2:
+        dr = rt.Context(rt.Scene.reference(arm, aspect_ratio=aspect).set_bvh_build("reference"), 0)
+        dr.render(W, H, 2)
+        o, _ = best_of(dr, W, H, spp)
+        line += f" | drawn axes (seed 1) {o:7.1f}"
+        dr.close()
         w, _ = best_of(ctx, W, H, spp, wavefront=True)
         line += f" | wavefront {w:7.1f}"
         nf = rt.Context(rt.Scene.reference(arm, aspect_ratio=aspect).set_walk_order(1), 0)
