@@ -599,7 +599,7 @@ def rank_main(a, be=None):
 
         # device-resident rate of this rank's share (framebuffer left in HBM), outside the timed region
         dev_ms = None
-        if rows and hasattr(be, "device_resident_ms"):
+        if rows and hasattr(be, "device_resident_ms") and not a.probe_coherent:
             dev_ms = be.device_resident_ms(ctx, local_rank, W, H, spp, tile, (srows, period), max(1, min(a.steps, 3)), kw)
 
         if rank == 0:

@@ -41,7 +41,7 @@ namespace rtf32 {
 
 /* waves per SIMD the f32 kernels are built for.  The Cornell variant V0 fits 4 (127 VGPRs, no spill).  The feature-rich variants do
  * not: held to 128 registers they spill 140-200 of them (and the reordering kernels missed the bound anyway: 3 and 2 waves), so
- * they are built for 3 like their f64 forms (measured: profiles/r03_f32_occupancy.txt). */
+ * they are built for 3 like their f64 forms (static figures: hipcc -Rpass-analysis=kernel-resource-usage, tools/kernel_resources.py). */
 #define RT_F32_WAVES(Cfg) ((Cfg::sweep && !Cfg::media && !Cfg::tex && !Cfg::msphere) ? 4 : 3)
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, RT_F32_WAVES(Cfg)) void rt_render_kernel_f32(RtSceneView sc, RtFrame f, rt_f64* __restrict__ partial, unsigned long long* __restrict__ counters) {

@@ -1391,7 +1391,9 @@ RT_HD uint32_t rt_quantize(double c) {
 /* work item -> (pixel, chunk): items are numbered so that 64 consecutive items
  * are an 8x8 pixel block of one chunk (rays of one wave start coherent). */
 RT_HD void rt_item_decode(const RtFrame& f, uint64_t item, uint32_t& px, uint32_t& py, uint32_t& chunk) {
+#if !defined(RT_NO_PROBE)
     if (f.probe) item = ((item >> 6) << 6) | ((item >> 6) & 63u); /* RtFrame::probe: 64 consecutive ids (one wave's) -> one item, one pixel per 8x8 block */
+#endif
     uint32_t bw = (f.tile_w + 7u) >> 3, bh = (f.tile_h + 7u) >> 3;
     uint64_t per_chunk = (uint64_t)bw * bh * 64u;
     chunk = (uint32_t)(item / per_chunk);

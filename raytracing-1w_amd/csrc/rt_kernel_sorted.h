@@ -90,6 +90,9 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
  * wave(s), so regeneration is coherent too.  Results cannot depend on the lane a path runs on
  * (a path is a pure function of its state; a pixel chunk's samples still run one after the other
  * and are summed in order), so the framebuffer is bit-identical to the unsorted kernel's. */
+#ifndef RT_SORTED_CARRY_RADIANCE
+#define RT_SORTED_CARRY_RADIANCE 0 /* A/B (RT1W_JIT_EXTRA_OPTS=-DRT_SORTED_CARRY_RADIANCE=1): round 3's form, the zero radiance carried across the loop */
+#endif
 #define RT_XCH_QW 26 /* qwords of per-path state exchanged */
 #ifndef RT_XCH_PARTS
 #define RT_XCH_PARTS 1 /* rounds the exchange is done in (LDS per workgroup = ceil(26 / parts) qwords x paths) */
@@ -254,10 +257,15 @@ __device__ __forceinline__ void rt_render_sorted_body(const RtSceneView& sc, con
         if (!retired) {
             /* a path's radiance is written by its terminal only (rt_path_shade: the emitting material never scatters), so it is zero here
              * and nothing of it is carried across the loop or through the exchange */
+#if !RT_SORTED_CARRY_RADIANCE
             path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+#endif
             rt_path_shade<Cfg>(sc, path, tr);
             if (!path.alive) {
                 sum = rt_v3d_add(sum, path.radiance); /* pixel_color += ray_color(..), main.rs:972-989 */
+#if RT_SORTED_CARRY_RADIANCE
+                path.radiance = rt_v3(RT_R(0.0), RT_R(0.0), RT_R(0.0));
+#endif
                 ++s;
             }
         }
