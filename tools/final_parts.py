@@ -60,7 +60,7 @@ for name, kw in CASES:
         ctx.render(800, 800, 2)
         best = 0
         for _ in range(2):
-            g, st = ctx.render(800, 800, 16)
+            g, st = ctx.render(800, 800, 64)
             best = max(best, st["paths"] / st["kernel_ms"] / 1e3)
         info = sc.info()
         print(f"{name:58s} {'SAH' if sah else 'ref'} nodes {info['n_nodes']:5d} V{st['variant']} seg/path {st['segments'] / st['paths']:.2f} {best:7.1f} Mpaths/s "
