@@ -198,7 +198,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_OUT_SUM 1u   /* write raw per-pixel sums (for sample-range sharding) instead of into_sampled means */
 #define RT1W_LDS_NODES 4u /* experiment: stack variants read node records from an LDS copy (scenes <= 1024 nodes); measured slower than the default */
 #define RT1W_GENERIC 8u   /* do not use a scene-specialised kernel even if the context has one (rt1w_context_specialise) */
-#define RT1W_WAVEFRONT 16u /* opt-in, big scenes (stack-walk variants) and the one-shot entries only: path state queued in HBM as SoA records, a trace kernel (round 3: the product's own walk by itself, 1.7x the vote-scheduled kernel of round 2, which RT1W_WF_TRACE=vote in the environment selects) + a shade kernel per bounce, a finish kernel for the tail (rt_wavefront.h); bit-identical to the default, measured 0.9x its speed on final_scene and 0.55x on random_scene (profiles/r03_wavefront_ab.txt).  Scenes that run a sweep kernel ignore the flag (stats.sorted bit 3 says what ran); rt1w_render_rows refuses it */
+#define RT1W_WAVEFRONT 16u /* opt-in, big scenes (stack-walk variants) and the one-shot entries only: path state queued in HBM as SoA records, a trace kernel + a shade kernel per bounce, a finish kernel for the tail; bit-identical to the default, measured 0.4-0.9x its speed (docs/LAB_NOTES.md).  Since round 4 the form lives in the diagnostics library librt1w_lab.so (csrc/wavefront.hip), which registers itself with librt1w.so when it is loaded: without it the flag answers RT1W_ERR_UNSUPPORTED.  Scenes that run a sweep kernel ignore the flag (stats.sorted bit 3 says what ran); rt1w_render_rows refuses it */
 #define RT1W_OUT_FRAME 32u /* rt1w_render only: `out_rgb` is the WHOLE image [height][width][3] (row 0 = j = 0) and the call writes just its tile's pixels at their image positions -- several contexts / processes fill one (shared, pinned) host frame: the host gather of the image-tiled multi-GPU job */
 #define RT1W_RNG_REFERENCE 64u /* PARITY MODE: draw from the reference's own generator instead of the Philox streams -- `StdRng::seed_from_u64(j * image_width + i)` (src/main.rs:964; ChaCha12, rand 0.8.4), one stream per pixel drawn on through all its samples in order (sample_offset must be 0, global_seed is ignored).  The frame is then the Rust program's own, pixel for pixel: the GPU reproduces rest_of_your_life.png.  Slower than the default (a lane owns a pixel for all its samples) */
 #define RT1W_CLASSIC_WALK 128u /* tests/ablation: sphere scenes (random_scene) walk their BVH with the pair walk of csrc/rt_walk_pair.h by default (box work and leaf work in separate phases, inner boxes in f32 rounded outward, every sphere gated by its group's own f64 box at the reference's moment: the same frames bit for bit, stats.sorted bit 7 says it ran); this flag keeps the one-entry-per-step walk.  Likewise scenes whose every ConstantMedium is bounded by a bare Sphere (final_scene) run stack-walk kernels built without the general boundary walks (rt_flat.h: RtCfgSphereMedia; stats.sorted bit 8); this flag keeps the general kernels */

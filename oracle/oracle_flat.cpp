@@ -199,6 +199,7 @@ extern "C" int orcflat_pair_walk(const void* nodes_, uint32_t n_nodes, uint32_t 
     std::vector<RtPwInner> inner;
     std::vector<RtPwGroup> groups;
     RtPwView pw;
+    std::memset(&pw, 0, sizeof pw);
     std::string why;
     if (!rt_pw_build(N, root, inner, groups, pw, why)) return -1;
     pw.inner = inner.data(); pw.groups = groups.data();

@@ -28,6 +28,17 @@ if not os.path.exists(LIB_PATH):
     )
 
 _lib = C.CDLL(LIB_PATH)
+_lab = None
+
+
+def load_lab():
+    """Load the diagnostics library librt1w_lab.so (the trace-only harness and the wavefront form: measured opt-ins that are not in the
+    product library).  Loading it registers the wavefront form with librt1w.so; RT1W_WAVEFRONT renders need it."""
+    global _lab
+    if _lab is None:
+        _lab = C.CDLL(os.path.join(os.path.dirname(LIB_PATH), "librt1w_lab.so"))
+    return _lab
+
 
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_STATE, ERR_CANCELLED = -1, -2, -3, -4, -5, -6
@@ -361,6 +372,8 @@ class Context:
     def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False,
                 strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False, probe_coherent=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
+        if wavefront:
+            load_lab()
         flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (CLASSIC_WALK if classic_walk else 0) | (PROBE_COHERENT if probe_coherent else 0) | (((variant + 1) << 8) if variant is not None else 0)
         sr, sp = strips if strips is not None else (0, 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp, 1 if f32 else 0, 0)

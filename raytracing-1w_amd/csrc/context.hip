@@ -29,7 +29,6 @@
 
 #include "rt1w.h"
 #include "rt_kernel_plain.h"
-#include "rt_wavefront.h"
 #include "scene.h"
 #include "jit.h"
 #include "rt1w_internal.h"
@@ -185,17 +184,11 @@ struct rt1w_context {
     int variant = 0;
     bool has_media = false, has_tex = false, has_msphere = false;
     uint32_t n_nodes = 0, scope_depth = 0;
-    /* wavefront form (rt_wavefront.h): two SoA path queues, per-sample radiance of one pass, device-side counters */
-    WfQueue wf_q[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
-    double* wf_rad = nullptr;
-    WfCounters* wf_counters = nullptr; unsigned long long* wf_hcounters = nullptr;
-    size_t wf_cap = 0;
-    WfRecs wf_recs = {nullptr, 0.0, 1.0}; void* d_wf_recs = nullptr; /* walk records of the big scenes (null: not eligible) */
-    int wf_grid_trace[22] = {0}, wf_grid_shade[3] = {0, 0, 0}, wf_grid_finish[3] = {0, 0, 0};
+    void* wf_state = nullptr; /* the wavefront form's own state (librt1w_lab.so: wavefront.hip), freed through its destroy hook */
     uint32_t stack_need = 0;
     int ref_grid[4] = {0, 0, 0, 0}; /* reference-stream kernels: sweep, stack walk, reordering V0, reordering every-feature */
     void* f32_scene = nullptr;   /* context_f32.hip: f32 copies of the scene arrays, built at the first f32 render */
-    bool f32_tried = false, wf_recs_tried = false; std::string wf_recs_error;
+    bool f32_tried = false;
     /* pair walk (rt_walk_pair.h): records of an eligible scene (sphere-only, variant 5), the kernel's grid */
     void* d_pw_inner = nullptr; void* d_pw_groups = nullptr;
     RtPwView pw{};
@@ -271,33 +264,6 @@ int ensure_f32_scene(rt1w_context* c) {
     }
     return RT1W_OK;
 }
-/* RT1W_WAVEFRONT: walk records of the vote-scheduled trace kernel, at the first wavefront render; eligible when every
- * MovingSphere has the same (time0, time1) */
-int ensure_wf_recs(rt1w_context* c) {
-    if (c->wf_recs.p) return RT1W_OK;
-    if (c->wf_recs_tried) { rt1w::set_error(c->wf_recs_error); return RT1W_ERR_UNSUPPORTED; }
-    c->wf_recs_tried = true;
-    std::vector<WfRec> recs(c->h_nodes.size());
-    bool ok_ms = true, seen = false;
-    double t0 = 0.0, t1 = 1.0;
-    for (size_t i = 0; i < recs.size(); ++i) {
-        const RtNode& n = c->h_nodes[i];
-        WfRec& r = recs[i];
-        r.kind = n.kind; r.b = n.b;
-        for (int k = 0; k < 6; ++k) r.d[k] = n.d[k];
-        r.d[6] = 0.0;
-        if ((n.kind & RT_KIND_MASK) == RT_MSPHERE) {
-            r.d[6] = n.e[2];
-            if (!seen) { t0 = n.e[0]; t1 = n.e[1]; seen = true; }
-            else if (memcmp(&t0, &n.e[0], 8) != 0 || memcmp(&t1, &n.e[1], 8) != 0) ok_ms = false;
-        }
-    }
-    if (!ok_ms) { c->wf_recs_error = "wavefront form: the scene's moving spheres do not share one shutter interval"; rt1w::set_error(c->wf_recs_error); return RT1W_ERR_UNSUPPORTED; }
-    if (!upload(&c->d_wf_recs, recs.data(), recs.size() * sizeof(WfRec))) { c->wf_recs_error = rt1w_last_error(); return RT1W_ERR_DEVICE; }
-    c->wf_recs.p = (const WfRec*)c->d_wf_recs; c->wf_recs.ms_time0 = t0; c->wf_recs.ms_time1 = t1;
-    return RT1W_OK;
-}
-
 int validate(const rt1w_context* c, const rt1w_render_params* p) {
     if (!c || !p) { rt1w::set_error("null argument"); return RT1W_ERR_INVALID; }
     if (p->width < 2 || p->height < 2) { rt1w::set_error("width and height must be >= 2 (u,v divide by W-1, H-1; main.rs:968-969)"); return RT1W_ERR_INVALID; }
@@ -586,131 +552,38 @@ int specialise_f32(rt1w_context* c, bool allow_compile) {
     return RT1W_OK;
 }
 
-/* ---- wavefront form (rt_wavefront.h) ---- */
-typedef void (*wf_trace_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, WfRecs);
-typedef void (*wf_shade_t)(RtSceneView, RtFrame, WfQueue, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
-/* trace kernels: [variant 2/3][scene has wrappers][stack capacity 16/32] */
-static wf_trace_t const g_wf_trace[3][2][2] = {
-    {{wf_trace<RtCfgV2, false, 16>, wf_trace<RtCfgV2, false, 32>}, {wf_trace<RtCfgV2, true, 16>, wf_trace<RtCfgV2, true, 32>}},
-    {{wf_trace<RtCfgV3, false, 16>, wf_trace<RtCfgV3, false, 32>}, {wf_trace<RtCfgV3, true, 16>, wf_trace<RtCfgV3, true, 32>}},
-    {{wf_trace<RtCfgV4, false, 16>, wf_trace<RtCfgV4, false, 32>}, {wf_trace<RtCfgV4, true, 16>, wf_trace<RtCfgV4, true, 32>}}};
-static wf_trace_t const g_wf_trace_lds[3][2] = {{wf_trace_lds<RtCfgV2, false>, wf_trace_lds<RtCfgV2, true>}, {wf_trace_lds<RtCfgV3, false>, wf_trace_lds<RtCfgV3, true>},
-                                                {wf_trace_lds<RtCfgV4, false>, wf_trace_lds<RtCfgV4, true>}};
-/* the plain trace kernels (the product's own walk by itself): V2, V3, V4, and V5 for scenes without wrappers */
-static wf_trace_t const g_wf_trace_plain[4] = {wf_trace_plain<RtCfgV2>, wf_trace_plain<RtCfgV3>, wf_trace_plain<RtCfgV4>, wf_trace_plain<RtCfgV5>};
-static wf_shade_t const g_wf_shade[3] = {wf_shade<RtCfgV2>, wf_shade<RtCfgV3>, wf_shade<RtCfgV4>};
-typedef void (*wf_finish_t)(RtSceneView, RtFrame, WfQueue, WfCounters*, uint32_t, uint32_t, double*);
-static wf_finish_t const g_wf_finish[3] = {wf_finish<RtCfgV2>, wf_finish<RtCfgV3>, wf_finish<RtCfgV4>};
-#define RT_WF_PASS_PATHS (16ull << 20) /* paths in flight per pass: 2 queues x 16 Mi x 128 B = 4 GiB */
+/* ---- wavefront form: lives in librt1w_lab.so (wavefront.hip), which registers itself here when it is loaded ---- */
+static rt1w_wf_render_fn g_wf_render = nullptr;
+static rt1w_wf_destroy_fn g_wf_destroy = nullptr;
 
-/* the wavefront form of one render: per chunk of samples, passes of <= RT_WF_PASS_PATHS paths; per pass
- * generate -> (trace -> shade) x max_depth with the queue lengths kept on the device; then the pass's samples are added
- * to the chunk sum in sample order */
 int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunch& L, double* d_out, rt1w_stats* stats) {
+    if (!g_wf_render) {
+        rt1w::set_error("RT1W_WAVEFRONT: the wavefront form (a measured, slower opt-in) is part of librt1w_lab.so -- load that library, it registers itself");
+        return RT1W_ERR_UNSUPPORTED;
+    }
     RtLane& l = c->lane[0];
-    const RtFrame& f = L.f;
-    const unsigned long long npix = L.npix;
-    const int v = L.variant == 5 ? 2 : L.variant; /* no kernels of its own for the wrapper-free variant: V2's cover it */
-    if (v < 2) { rt1w::set_error("the wavefront form exists for the stack-walk variants only"); return RT1W_ERR_INVALID; }
-    if (npix > RT_WF_PASS_PATHS) { rt1w::set_error("wavefront form: tile larger than one pass (render it in strips)"); return RT1W_ERR_UNSUPPORTED; }
-    if (f.max_depth > WF_MAX_BOUNCES) { rt1w::set_error("wavefront form: max_depth above WF_MAX_BOUNCES"); return RT1W_ERR_UNSUPPORTED; }
-    const uint32_t s_pass_max = (uint32_t)(RT_WF_PASS_PATHS / npix);
-    const uint32_t n_pass = (f.chunk + s_pass_max - 1u) / s_pass_max;      /* passes per chunk, of (nearly) equal size */
-    const uint32_t s_pass = (f.chunk + n_pass - 1u) / n_pass;
-    const size_t cap = (size_t)npix * s_pass;
-    if (cap > c->wf_cap) {
-        for (int k = 0; k < 2; ++k) {
-            if (c->wf_q[k].f) (void)hipFree(c->wf_q[k].f);
-            if (c->wf_q[k].u) (void)hipFree(c->wf_q[k].u);
-            c->wf_q[k] = WfQueue{nullptr, nullptr, 0};
-        }
-        if (c->wf_rad) (void)hipFree(c->wf_rad);
-        c->wf_rad = nullptr; c->wf_cap = 0;
-        for (int k = 0; k < 2; ++k) {
-            if (!hip_ok(hipMalloc((void**)&c->wf_q[k].f, cap * WF_NF * sizeof(double)), "hipMalloc(path queue)") ||
-                !hip_ok(hipMalloc((void**)&c->wf_q[k].u, cap * WU_NU * sizeof(uint32_t)), "hipMalloc(path queue)")) return RT1W_ERR_NOMEM;
-            c->wf_q[k].cap = cap;
-        }
-        if (!hip_ok(hipMalloc((void**)&c->wf_rad, cap * 3 * sizeof(double)), "hipMalloc(sample radiance)")) return RT1W_ERR_NOMEM;
-        c->wf_cap = cap;
-    }
-    if (!c->wf_counters) {
-        if (!hip_ok(hipMalloc((void**)&c->wf_counters, sizeof(WfCounters)), "hipMalloc(counters)") ||
-            !hip_ok(hipHostMalloc((void**)&c->wf_hcounters, 2 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(counters)")) return RT1W_ERR_NOMEM;
-    }
-    /* trace kernel: the plain one (the product's walk by itself; default since round 3), or the vote-scheduled one of round 2
-     * (RT1W_WF_TRACE=vote: kept for the A/B, profiles/r03_wavefront_*) */
-    const char* wf_trace_env = getenv("RT1W_WF_TRACE");
-    const bool plain_trace = !(wf_trace_env && wf_trace_env[0] == 'v');
-    if (!plain_trace) { const int rcw = ensure_wf_recs(c); if (rcw < 0) return rcw; } /* the plain kernel reads the flat nodes themselves */
-    const bool lds_recs = !plain_trace && c->n_nodes <= RT_WF_LDS_NODES && c->stack_need <= 16u && !getenv("RT1W_WF_NO_LDS");
-    const int tblock = lds_recs ? RT_WF_LDS_BLOCK : RT_BLOCK;
-    const wf_trace_t trace = plain_trace ? g_wf_trace_plain[L.variant == 5 ? 3 : v - 2]
-                           : lds_recs ? g_wf_trace_lds[v - 2][c->scope_depth > 0u ? 1 : 0]
-                                      : g_wf_trace[v - 2][c->scope_depth > 0u ? 1 : 0][c->stack_need <= 16u ? 0 : 1];
-    const wf_shade_t shade = g_wf_shade[v - 2];
-    const int gi = plain_trace ? 18 + (L.variant == 5 ? 3 : v - 2)
-                 : lds_recs ? 12 + (v - 2) * 2 + (c->scope_depth > 0u ? 1 : 0) : (v - 2) * 4 + (c->scope_depth > 0u ? 2 : 0) + (c->stack_need <= 16u ? 0 : 1);
-    if (!c->wf_grid_trace[gi] || !c->wf_grid_shade[v - 2]) {
-        int per_cu = 0, per_cu_s = 0;
-        hipDeviceProp_t prop;
-        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace, tblock, 0), "occupancy query") ||
-            !hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, shade, RT_BLOCK, 0), "occupancy query") ||
-            !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
-        c->wf_grid_trace[gi] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
-        c->wf_grid_shade[v - 2] = prop.multiProcessorCount * (per_cu_s < 1 ? 1 : per_cu_s) * 2; /* grid-stride; short blocks */
-    }
-    const int grid_t = c->wf_grid_trace[gi], grid_s = c->wf_grid_shade[v - 2];
-    const wf_finish_t finish = g_wf_finish[v - 2];
-    if (!c->wf_grid_finish[v - 2]) {
-        int per_cu = 0;
-        hipDeviceProp_t prop;
-        if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finish, RT_BLOCK, 0), "occupancy query") ||
-            !hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) return RT1W_ERR_DEVICE;
-        c->wf_grid_finish[v - 2] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
-    }
-    uint32_t wf_bounces_want = plain_trace ? RT_WF_BOUNCES_PLAIN : RT_WF_BOUNCES;
-    if (const char* e = getenv("RT1W_WF_BOUNCES")) { const int x = atoi(e); if (x >= 1 && x <= (int)WF_MAX_BOUNCES) wf_bounces_want = (uint32_t)x; }
-    const uint32_t wf_bounces = f.max_depth < wf_bounces_want ? f.max_depth : wf_bounces_want;
-    if (!hip_ok(hipMemsetAsync(&c->wf_counters->segs, 0, sizeof(unsigned long long), l.stream), "counter reset")) return RT1W_ERR_DEVICE;
+    rt1w_wf_call k;
+    memset(&k, 0, sizeof k);
+    k.device = c->device; k.view = &c->view; k.frame = &L.f; k.npix = L.npix; k.variant = L.variant;
+    k.n_nodes = c->n_nodes; k.scope_depth = c->scope_depth; k.stack_need = c->stack_need;
+    k.h_nodes = c->h_nodes.data(); k.n_h_nodes = (uint32_t)c->h_nodes.size();
+    k.stream = (void*)l.stream; k.d_partial = l.d_partial; k.state = &c->wf_state; k.stats = stats;
     (void)hipEventRecord(l.ev0, l.stream);
-    for (uint32_t ch = 0; ch < f.n_chunks; ++ch) {
-        const uint32_t s_begin = ch * f.chunk;
-        const uint32_t s_cnt = s_begin + f.chunk < f.spp ? f.chunk : f.spp - s_begin;
-        for (uint32_t s0 = 0; s0 < s_cnt; s0 += s_pass) {
-            const uint32_t s_n = s_cnt - s0 < s_pass ? s_cnt - s0 : s_pass;
-            const unsigned long long n0 = npix * s_n;
-            hipLaunchKernelGGL(wf_init_counters, dim3(1), dim3(128), 0, l.stream, c->wf_counters, f.max_depth ? n0 : 0ull);
-            hipLaunchKernelGGL(wf_generate, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, l.stream, c->view, f, c->wf_q[0], s_begin + s0, s_n, c->wf_rad);
-            for (uint32_t b = 0; b < wf_bounces; ++b) {
-                hipLaunchKernelGGL(trace, dim3(grid_t), dim3(tblock), 0, l.stream, c->view, f, c->wf_q[b & 1u], c->wf_counters, b, s_begin + s0, c->wf_recs);
-                hipLaunchKernelGGL(shade, dim3(grid_s), dim3(RT_BLOCK), 0, l.stream, c->view, f, c->wf_q[b & 1u], c->wf_q[(b + 1u) & 1u], c->wf_counters, b,
-                                   s_begin + s0, c->wf_rad);
-            }
-            /* whatever is still alive after the wavefront bounces runs to its end in one launch */
-            if (wf_bounces < f.max_depth)
-                hipLaunchKernelGGL(finish, dim3(c->wf_grid_finish[v - 2]), dim3(RT_BLOCK), 0, l.stream, c->view, f, c->wf_q[wf_bounces & 1u], c->wf_counters,
-                                   wf_bounces, s_begin + s0, c->wf_rad);
-            hipLaunchKernelGGL(wf_chunk_sum, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, l.stream, (const double*)c->wf_rad,
-                               l.d_partial + (size_t)ch * npix * 3, npix, s_n, s0 == 0u ? 1u : 0u);
-        }
-    }
+    const int rc = g_wf_render(&k);                /* enqueues generate / trace / shade / finish / chunk sums on the lane's stream */
+    if (rc < 0) return rc;
     {
         unsigned int rb = 256;
-        unsigned int rg = (unsigned int)((npix + rb - 1) / rb);
-        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, npix, f.n_chunks, f.spp,
+        unsigned int rg = (unsigned int)((L.npix + rb - 1) / rb);
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, L.npix, L.f.n_chunks, L.f.spp,
                            (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
     }
     (void)hipEventRecord(l.ev1, l.stream);
-    if (!hip_ok(hipGetLastError(), "kernel launch") ||
-        !hip_ok(hipMemcpyAsync(c->wf_hcounters + 1, &c->wf_counters->segs, sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream), "counter copy") ||
-        !hip_ok(hipStreamSynchronize(l.stream), "wavefront render")) return RT1W_ERR_DEVICE;
+    if (!hip_ok(hipGetLastError(), "kernel launch") || !hip_ok(hipStreamSynchronize(l.stream), "wavefront render")) return RT1W_ERR_DEVICE;
     if (stats) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, l.ev0, l.ev1);
-        stats->paths = npix * f.spp; stats->segments = c->wf_hcounters[1]; stats->kernel_ms = ms;
-        stats->chunk = f.chunk; stats->n_chunks = f.n_chunks; stats->grid = (uint32_t)grid_t; stats->block = (uint32_t)tblock;
-        stats->variant = (uint32_t)v; stats->sorted = 8u | (lds_recs ? 2u : 0u) | (plain_trace ? 64u : 0u); /* bit 3: wavefront form; bit 1: walk records in LDS; bit 6: plain trace kernel */
+        stats->paths = L.npix * L.f.spp; stats->segments = k.h_segments ? *k.h_segments : 0ull; stats->kernel_ms = ms;
+        stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
     }
     return RT1W_OK;
 }
@@ -864,7 +737,7 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
         }
     } else c->pw_why = "not a wrapper-free, media-free scene of more than 64 nodes, or its tree is deeper than the pair walk's stack";
     /* the opt-in modes' own data (f32 scene arrays, the wavefront form's walk records) are built at their first use:
-     * ensure_f32_scene / ensure_wf_recs */
+     * ensure_f32_scene; the wavefront form's in librt1w_lab.so */
     c->h_nodes = s->flat_nodes; c->h_lights = s->flat_lights; c->h_materials = s->materials; c->h_textures = s->textures; c->h_perlin = s->perlin;
     if (rt1w::jit_eligible(*s)) {
         c->jit_src = rt1w::jit_source(*s);
@@ -879,9 +752,8 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
 void rt1w_context_destroy(rt1w_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images, c->d_out,
-                    c->wf_q[0].f, c->wf_q[0].u, c->wf_q[1].f, c->wf_q[1].u, c->wf_rad, c->wf_counters, c->d_wf_recs};
-    if (c->wf_hcounters) (void)hipHostFree(c->wf_hcounters);
+    void* bufs[] = {c->d_nodes, c->d_lights, c->d_materials, c->d_textures, c->d_perlin, c->d_images, c->d_out};
+    if (c->wf_state && g_wf_destroy) g_wf_destroy(c->wf_state);
     for (void* b : bufs) if (b) (void)hipFree(b);
     rt1w_internal_f32_destroy(c->f32_scene);
     if (c->d_pw_inner) (void)hipFree(c->d_pw_inner);
@@ -1124,6 +996,7 @@ int rt1w_host_register(void* p, uint64_t bytes) {
 int rt1w_host_unregister(void* p) { if (p && !hip_ok(hipHostUnregister(p), "hipHostUnregister")) return RT1W_ERR_DEVICE; return RT1W_OK; }
 
 /* for walk_lab.hip (diagnostics): the scene view the kernels get, and the device */
+void rt1w_internal_register_wavefront(rt1w_wf_render_fn render, rt1w_wf_destroy_fn destroy) { g_wf_render = render; g_wf_destroy = destroy; }
 const void* rt1w_internal_view(const rt1w_context* c) { return &c->view; }
 int rt1w_internal_device(const rt1w_context* c) { return c->device; }
 

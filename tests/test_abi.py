@@ -28,12 +28,12 @@ def test_library_exports_every_declared_symbol(rt):
 
 def test_library_exports_nothing_else(rt):
     """librt1w.so is built with -fvisibility=hidden and a linker version script (csrc/librt1w.map): its dynamic symbol table holds the
-    entries include/rt1w.h declares plus the three hooks of csrc/rt1w_internal.h (for the diagnostics library librt1w_lab.so) and
-    nothing else -- no C++ internals, no kernel host stubs, no unprefixed helpers, no laboratory (`rt1w_lab_*` live in librt1w_lab.so)."""
+    entries include/rt1w.h declares plus the four hooks of csrc/rt1w_internal.h (for the diagnostics library librt1w_lab.so) and
+    nothing else -- no C++ internals, no kernel host stubs, no unprefixed helpers, no laboratory (`rt1w_lab_*` and the wavefront form's kernels live in librt1w_lab.so)."""
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", rt.LIB_PATH]).decode()
     exported = sorted({line.split()[-1] for line in out.splitlines() if line.strip()})
-    internal = ["rt1w_internal_device", "rt1w_internal_set_error", "rt1w_internal_view"]
+    internal = ["rt1w_internal_device", "rt1w_internal_register_wavefront", "rt1w_internal_set_error", "rt1w_internal_view"]
     assert exported == sorted(set(declared_functions()) | set(internal)), sorted(set(exported) ^ (set(declared_functions()) | set(internal)))
     lab = os.path.join(os.path.dirname(rt.LIB_PATH), "librt1w_lab.so")
     lab_syms = subprocess.check_output(["nm", "-D", "--defined-only", lab]).decode()

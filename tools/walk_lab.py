@@ -14,7 +14,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rt = importlib.import_module("raytracing-1w_amd")
-L = C.CDLL(os.path.join(os.path.dirname(rt.LIB_PATH), "librt1w_lab.so"))  # the diagnostics library (links librt1w.so, already loaded)
+L = rt.load_lab()  # the diagnostics library (links librt1w.so, already loaded)
 _P = C.c_void_p
 L.rt1w_lab_create.argtypes = [_P, _P, C.POINTER(_P)]
 L.rt1w_lab_destroy.argtypes = [_P]
