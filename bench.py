@@ -422,7 +422,7 @@ def tiled_extra(be, dist, rank, world, local_rank, key, W, H, spp, steps, warmup
             frame = sharding.SharedFrame(name, W, H, False, rt)
         host = frame.array
         y0, rows, srows, period = sharding.interleaved_tile(H, world, rank)
-        kw = dict(max_depth=DEPTH, chunk=rt.default_chunk(W, H, spp))
+        kw = dict(max_depth=DEPTH, chunk=scene.default_chunk(W, H, spp))
 
         def step():
             return ctx.render(W, H, spp, tile=(0, y0, W, rows), strips=(srows, period), frame=host, **kw)[1] if rows else None
@@ -544,7 +544,7 @@ def rank_main(a, be=None):
     else:
         host = be.host_frame(H, W)
     y0, rows, srows, period = sharding.interleaved_tile(H, world, rank)
-    chunk = rt.default_chunk(W, H, spp)                                  # the whole frame's chunking: same sums as one GPU
+    chunk = scene.default_chunk(W, H, spp)                               # the whole frame's chunking (rt1w_scene_default_chunk): same sums as one GPU
     kw = dict(max_depth=DEPTH, generic=a.generic, chunk=chunk)
     if a.probe_coherent:
         kw["probe_coherent"] = True

@@ -213,7 +213,7 @@ typedef struct rt1w_render_params {
     uint32_t sample_offset;         /* first absolute sample index; 0 unless sharding samples */
     uint32_t max_depth;             /* MAX_DEPTH = 50 (src/main.rs:801) */
     uint32_t global_seed;
-    uint32_t chunk;                 /* samples per work item, 0 = library default (rt1w_default_chunk) */
+    uint32_t chunk;                 /* samples per work item, 0 = library default (rt1w_scene_default_chunk) */
     uint32_t flags;                 /* RT1W_OUT_* */
     /* Row-interleaved tile, for tiling ONE image over several GPUs with balanced load (the reference hands rows to rayon
      * workers, src/main.rs:957-963; Cornell rows differ in cost by region): the tile's rows are strips of `strip_rows`
@@ -222,7 +222,8 @@ typedef struct rt1w_render_params {
      * Both 0: an ordinary contiguous tile.  One launch renders all of the rank's strips. */
     uint32_t strip_rows, strip_period;
     uint32_t precision;             /* RT1W_PRECISION_*: 0 = f64, the reference's `type Float = f64` (src/main.rs:1) */
-    uint32_t reserved;              /* must be 0 */
+    uint32_t partial_mib;           /* memory-constrained hosts / tests: upper bound, in MiB, of the buffer of chunk partial sums (24 B per work item); 0 = 8192.
+                                       A render that needs more runs as several passes over sample ranges -- the same bits (rt1w_scene_default_chunk) */
 } rt1w_render_params;
 #define RT1W_PRECISION_F64 0u
 /* the reference's switch set the other way, `type Float = f32`: rays, hit records, boxes, camera and colours in f32 (the
@@ -247,8 +248,17 @@ typedef struct rt1w_stats {
                               workgroup at the end of every slice of the stack walk */
 } rt1w_stats;
 
-/* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md */
+/* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md.  This is the scene-independent rule (what the
+ * small scenes' reordering kernels run with); see rt1w_scene_default_chunk for what a render of a given scene uses */
 uint32_t rt1w_default_chunk(uint32_t tile_w, uint32_t tile_h, uint32_t spp);
+/* The work-item size rt1w_render* use for THIS scene when rt1w_render_params.chunk is 0 (the samples of a pixel are summed per work
+ * item, then the items in order: src/main.rs:966-992 sums them all in order, which is the case chunk = 1).  Scenes that run a
+ * stack-walk kernel (more than 64 nodes) take ONE sample per item: a lane whose path ended fetches its next item with the other free
+ * lanes of its wave, so they restart on neighbouring pixels (coherent camera rays; measured +8-15 % on final_scene / random_scene),
+ * and the pixel sum is the reference's own sequential sum; scenes on the sweep kernels keep rt1w_default_chunk.  Renders whose
+ * partial sums would not fit 8 GiB run as several passes over sample ranges with the same bits.  A host that tiles one image over
+ * several GPUs passes this value (for the WHOLE frame) as `chunk` to every tile.  Committed scenes only (0 otherwise). */
+uint32_t rt1w_scene_default_chunk(const rt1w_scene* s, uint32_t tile_w, uint32_t tile_h, uint32_t spp);
 
 /* Renders the tile into caller memory: out_rgb[(y - y0) * tile_w + (x - x0)][3],
  * row 0 = j = y0.  Values are the reference's `pixel_color.into_sampled(spp)`

@@ -64,7 +64,7 @@ class Rt1wError(RuntimeError):
 class RenderParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "width", "height", "x0", "y0", "tile_w", "tile_h", "spp", "sample_offset",
-        "max_depth", "global_seed", "chunk", "flags", "strip_rows", "strip_period", "precision", "reserved")]
+        "max_depth", "global_seed", "chunk", "flags", "strip_rows", "strip_period", "precision", "partial_mib")]
 
 
 class SpecialiseInfo(C.Structure):
@@ -140,6 +140,7 @@ _sig("rt1w_context_destroy", None, _P)
 _sig("rt1w_context_specialise", C.c_int, _P, C.c_uint32, C.POINTER(SpecialiseInfo))
 _sig("rt1w_scene_kernel_key", C.c_int, _P, C.c_char * 24)
 _sig("rt1w_default_chunk", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("rt1w_scene_default_chunk", C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("rt1w_render", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_device", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
 _sig("rt1w_render_u8", C.c_int, _P, C.POINTER(RenderParams), _P, C.POINTER(Stats))
@@ -323,6 +324,11 @@ class Scene:
         _ck(_lib.rt1w_scene_set_walk_order(self._h, int(near_far)))   # 0 reference, 1 near-far (frames identical on all tested scenes, not provably; segment counts may differ), 2 near-far everywhere
         return self
 
+    def default_chunk(self, tile_w, tile_h, spp):
+        """Samples per work item the renders of THIS scene use when `chunk` is 0 (rt1w_scene_default_chunk): 1 for scenes on the
+        stack-walk kernels, the scene-independent rule (default_chunk) for the others."""
+        return int(_lib.rt1w_scene_default_chunk(self._h, tile_w, tile_h, spp))
+
     def bvh_topology(self):
         """The trees of the opt-in SAH / best-axis builds as one int32 stream (rt1w_scene_get_bvh_topology); empty for the reference's build."""
         n = int(_lib.rt1w_scene_get_bvh_topology(self._h, None, 0))
@@ -376,7 +382,7 @@ class Context:
             load_lab()
         flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (CLASSIC_WALK if classic_walk else 0) | (PROBE_COHERENT if probe_coherent else 0) | (((variant + 1) << 8) if variant is not None else 0)
         sr, sp = strips if strips is not None else (0, 0)
-        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp, 1 if f32 else 0, 0)
+        return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp, 1 if f32 else 0, int(partial_mib))
 
     def specialise(self, cached_only=False):
         """Load (from the kernel cache) or compile (hiprtc, 3-5 s) the kernel specialised for this scene's topology
@@ -395,14 +401,14 @@ class Context:
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
                variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False, strips=None, out=None, frame=None,
-               reference_stream=False, f32=False, classic_walk=False, probe_coherent=False):
+               reference_stream=False, f32=False, classic_walk=False, probe_coherent=False, partial_mib=0):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict).
         probe_coherent: measurement mode RT1W_PROBE_COHERENT -- the returned array is NOT the image.
         strips=(strip_rows, strip_period): row-interleaved tile (tile row r = image row y0 + r//strip_rows*strip_period +
         r%strip_rows).  out: caller's array for the packed tile (e.g. pinned_empty).  frame: caller's WHOLE image
         [height, width, 3]; the tile's pixels are written at their image positions (RT1W_OUT_FRAME) and `frame` is returned."""
         p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront,
-                         strips, frame is not None, reference_stream, f32, classic_walk, probe_coherent)
+                         strips, frame is not None, reference_stream, f32, classic_walk, probe_coherent, partial_mib)
         if frame is not None:
             assert frame.dtype == np.float64 and frame.shape == (height, width, 3) and frame.flags.c_contiguous
             out = frame

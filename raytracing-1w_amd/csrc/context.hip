@@ -91,15 +91,17 @@ __global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_k
 /* Sum the chunk partials of each pixel in chunk order; then Color::into_sampled
  * (color.rs:14-21) unless raw sums were asked for. */
 __global__ void rt_resolve_kernel(const double* __restrict__ partial, double* __restrict__ out,
-                                  unsigned long long npix, uint32_t n_chunks, uint32_t spp, uint32_t out_sum) {
+                                  unsigned long long npix, uint32_t n_chunks, uint32_t spp, uint32_t out_sum, uint32_t carry) {
+    /* carry bit 0: `out` already holds the raw sums of earlier sample passes, the chunks of this pass are added to them IN ORDER (the same
+     * sequence of additions as one pass over all chunks: same bits); bit 1: more passes follow, `out` stays raw */
     unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    RtV3 total = rt_v3(0.0, 0.0, 0.0);
+    RtV3 total = (carry & 1u) ? rt_v3(out[p * 3 + 0], out[p * 3 + 1], out[p * 3 + 2]) : rt_v3(0.0, 0.0, 0.0);
     for (uint32_t c = 0; c < n_chunks; ++c) {
         const double* src = partial + ((unsigned long long)c * npix + p) * 3ull;
         total = total + rt_v3(src[0], src[1], src[2]);
     }
-    if (!out_sum) total = rt_into_sampled(total, spp);
+    if (!out_sum && !(carry & 2u)) total = rt_into_sampled(total, spp);
     out[p * 3 + 0] = total.x; out[p * 3 + 1] = total.y; out[p * 3 + 2] = total.z;
 }
 
@@ -274,7 +276,6 @@ int validate(const rt1w_context* c, const rt1w_render_params* p) {
     if ((p->strip_rows == 0) != (p->strip_period == 0) || p->strip_period < p->strip_rows) {
         rt1w::set_error("strip_rows / strip_period: both 0, or 0 < strip_rows <= strip_period"); return RT1W_ERR_INVALID;
     }
-    if (p->reserved != 0u) { rt1w::set_error("rt1w_render_params.reserved must be 0"); return RT1W_ERR_INVALID; }
     if (p->precision != RT1W_PRECISION_F64 && p->precision != RT1W_PRECISION_F32) { rt1w::set_error("unknown precision"); return RT1W_ERR_UNSUPPORTED; }
     if (p->strip_rows) {
         const uint64_t last = (uint64_t)p->tile_h - 1u;
@@ -300,7 +301,7 @@ __global__ void rt_debug_texture_kernel(RtSceneView sc, int mode, uint32_t tex, 
     out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
 }
 
-__global__ void rt_init_counters_kernel(unsigned long long* ctr, unsigned long long next_item) { ctr[0] = next_item; ctr[1] = 0ull; }
+__global__ void rt_init_counters_kernel(unsigned long long* ctr, unsigned long long next_item, uint32_t keep_segments) { ctr[0] = next_item; if (!keep_segments) ctr[1] = 0ull; }
 
 bool lane_init(RtLane& l) {
     if (l.stream) return true;
@@ -323,7 +324,10 @@ void lane_destroy(RtLane& l) {
     l = RtLane();
 }
 
-struct RtLaunch { RtFrame f; unsigned long long npix; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false, sphere_media = false, ss = false; };
+#ifndef RT_PARTIAL_BUDGET
+#define RT_PARTIAL_BUDGET (8ull << 30)
+#endif
+struct RtLaunch { RtFrame f; unsigned long long npix; unsigned long long partial_budget = RT_PARTIAL_BUDGET; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false, sphere_media = false, ss = false; };
 int specialise_f32(rt1w_context* c, bool allow_compile);
 
 /* what the launch will need, without launching: frame, variant, launch shape */
@@ -335,10 +339,13 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     f.global_seed = p->global_seed;
     f.strip_rows = p->strip_rows; f.strip_period = p->strip_period;
     f.probe = (p->flags & RT1W_PROBE_COHERENT) ? 1u : 0u;
-    f.chunk = p->chunk ? p->chunk : rt1w_default_chunk(p->tile_w, p->tile_h, p->spp);
+    /* stack-walk scenes: one sample per work item (include/rt1w.h: rt1w_scene_default_chunk), except for the wavefront form, whose passes are
+     * per chunk; the reference stream sets its own below */
+    f.chunk = p->chunk ? p->chunk : ((c->variant >= 2 && !(p->flags & RT1W_WAVEFRONT)) ? 1u : rt1w_default_chunk(p->tile_w, p->tile_h, p->spp));
     if (f.chunk > f.spp) f.chunk = f.spp;
     f.n_chunks = (f.spp + f.chunk - 1u) / f.chunk;
     L.npix = (unsigned long long)f.tile_w * f.tile_h;
+    L.partial_budget = p->partial_mib ? ((unsigned long long)p->partial_mib << 20) : RT_PARTIAL_BUDGET;
     L.ref = false; L.f32 = false;
     if (p->precision == RT1W_PRECISION_F32) {
         if (p->flags & (RT1W_RNG_REFERENCE | RT1W_WAVEFRONT | RT1W_LDS_NODES)) { rt1w::set_error("RT1W_PRECISION_F32 has the default kernels only"); return RT1W_ERR_INVALID; }
@@ -412,8 +419,19 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     return RT1W_OK;
 }
 
+/* chunk partial sums: [chunk][pixel][3] f64.  A render whose partial sums would exceed this budget runs as several PASSES over
+ * consecutive chunk ranges (= sample ranges): every pass is one launch of the persistent kernel into the same buffer, and the resolve
+ * kernel adds the pass's chunks to the running pixel sums in order -- the same additions in the same order as one pass, so the same
+ * bits whatever the budget (one sample per work item on a big frame at 10 000 spp would otherwise need 150 GB) */
+uint32_t chunks_per_pass(const RtLaunch& L, unsigned long long bytes = RT_PARTIAL_BUDGET) {
+    const unsigned long long per_chunk = L.npix * 3ull * sizeof(double);
+    unsigned long long n = per_chunk ? bytes / per_chunk : 1ull;
+    if (n < 1ull) n = 1ull;
+    return n >= L.f.n_chunks ? L.f.n_chunks : (uint32_t)n;
+}
+
 int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
-    size_t need = (size_t)L.npix * L.f.n_chunks * 3 * sizeof(double);
+    size_t need = (size_t)L.npix * chunks_per_pass(L, L.partial_budget) * 3 * sizeof(double);
     if (need > l.partial_bytes) {
         if (l.d_partial) (void)hipFree(l.d_partial);
         l.d_partial = nullptr; l.partial_bytes = 0;
@@ -425,45 +443,55 @@ int lane_reserve_partial(RtLane& l, const RtLaunch& L) {
 
 /* enqueue on the lane's stream: counters, trace kernel, resolve into d_out, counters back to pinned memory.  No host wait. */
 int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const RtLaunch& L, double* d_out) {
-    hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block);
     (void)hipEventRecord(l.ev0, l.stream);
+    const uint32_t cpp = chunks_per_pass(L, l.partial_bytes < L.partial_budget ? l.partial_bytes : L.partial_budget); /* what the lane's buffer holds (lane_reserve_partial), within the caller's bound */
+    const uint32_t n_pass = (L.f.n_chunks + cpp - 1u) / cpp;
+    for (uint32_t pass = 0; pass < n_pass; ++pass) {
+    /* this pass's chunks as a frame of their own: samples [c0 * chunk, ...) of the call, absolute sample indices through sample_offset */
+    RtFrame PF = L.f;
+    const uint32_t c0 = pass * cpp;
+    PF.n_chunks = L.f.n_chunks - c0 < cpp ? L.f.n_chunks - c0 : cpp;
+    PF.sample_offset = L.f.sample_offset + c0 * L.f.chunk;
+    PF.spp = (L.f.spp - c0 * L.f.chunk < PF.n_chunks * L.f.chunk) ? L.f.spp - c0 * L.f.chunk : PF.n_chunks * L.f.chunk;
+    hipLaunchKernelGGL(rt_init_counters_kernel, dim3(1), dim3(1), 0, l.stream, l.d_counters, (unsigned long long)L.grid * L.block, pass ? 1u : 0u);
     if (L.f32 && L.jit) {
         unsigned char view32[512];
         if (!c->f32_scene || rt1w_internal_f32_view(c->f32_scene, view32, sizeof view32) == 0u) { rt1w::set_error("single-precision scene missing"); return RT1W_ERR_DEVICE; }
-        RtFrame frame = L.f;
+        RtFrame frame = PF;
         double* partial = l.d_partial;
         unsigned long long* counters = l.d_counters;
         void* args[] = {view32, &frame, &partial, &counters};
         if (!hip_ok(hipModuleLaunchKernel(c->jit32_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised f32 kernel launch")) return RT1W_ERR_DEVICE;
     } else if (L.f32) {
-        if (!c->f32_scene || rt1w_internal_f32_launch(c->f32_scene, L.variant, L.pw ? 2 : (L.sorted ? 1 : 0), &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
+        if (!c->f32_scene || rt1w_internal_f32_launch(c->f32_scene, L.variant, L.pw ? 2 : (L.sorted ? 1 : 0), &PF, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
             rt1w::set_error("single-precision kernel launch failed"); return RT1W_ERR_DEVICE;
         }
     } else if (L.ref) {
         if (rt1w_internal_ref_sizeof(0) != sizeof(RtSceneView) || rt1w_internal_ref_sizeof(1) != sizeof(RtFrame) ||
-            rt1w_internal_ref_launch(L.variant == 3 ? 1 : (L.sorted ? (L.variant == 0 ? 2 : 3) : 0), &c->view, &L.f, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
+            rt1w_internal_ref_launch(L.variant == 3 ? 1 : (L.sorted ? (L.variant == 0 ? 2 : 3) : 0), &c->view, &PF, l.d_partial, l.d_counters, L.grid, l.stream) != 0) {
             rt1w::set_error("reference-stream kernel launch failed"); return RT1W_ERR_DEVICE;
         }
     } else if (L.jit) {
         RtSceneView view = c->view;
-        RtFrame frame = L.f;
+        RtFrame frame = PF;
         double* partial = l.d_partial;
         unsigned long long* counters = l.d_counters;
         void* args[] = {&view, &frame, &partial, &counters};
         if (!hip_ok(hipModuleLaunchKernel(c->jit_fn, (unsigned)L.grid, 1, 1, (unsigned)L.block, 1, 1, 0, l.stream, args, nullptr), "specialised kernel launch")) return RT1W_ERR_DEVICE;
     } else if (L.pw) {
-        if (L.ss) hipLaunchKernelGGL(rt_render_kernel_pw_ss<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
-        else hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, L.f, l.d_partial, l.d_counters);
+        if (L.ss) hipLaunchKernelGGL(rt_render_kernel_pw_ss<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, PF, l.d_partial, l.d_counters);
+        else hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, PF, l.d_partial, l.d_counters);
     } else {
         hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.ss ? g_kernels_ss[L.sphere_media ? 1 : 0][L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant]))),
-                           dim3(L.grid), dim3(L.block), 0, l.stream, c->view, L.f, l.d_partial, l.d_counters);
+                           dim3(L.grid), dim3(L.block), 0, l.stream, c->view, PF, l.d_partial, l.d_counters);
     }
     {
         unsigned int rb = 256;
         unsigned int rg = (unsigned int)((L.npix + rb - 1) / rb);
-        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, L.npix, L.f.n_chunks,
-                           L.f.spp, (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
+        hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, L.npix, PF.n_chunks,
+                           L.f.spp, (p->flags & RT1W_OUT_SUM) ? 1u : 0u, (pass ? 1u : 0u) | (pass + 1u < n_pass ? 2u : 0u));
     }
+    } /* passes */
     (void)hipEventRecord(l.ev1, l.stream);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return RT1W_ERR_DEVICE;
     if (!hip_ok(hipMemcpyAsync(l.h_counters, l.d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, l.stream), "counter copy")) return RT1W_ERR_DEVICE;
@@ -575,7 +603,7 @@ int render_wavefront(rt1w_context* c, const rt1w_render_params* p, const RtLaunc
         unsigned int rb = 256;
         unsigned int rg = (unsigned int)((L.npix + rb - 1) / rb);
         hipLaunchKernelGGL(rt_resolve_kernel, dim3(rg), dim3(rb), 0, l.stream, l.d_partial, d_out, L.npix, L.f.n_chunks, L.f.spp,
-                           (p->flags & RT1W_OUT_SUM) ? 1u : 0u);
+                           (p->flags & RT1W_OUT_SUM) ? 1u : 0u, 0u);
     }
     (void)hipEventRecord(l.ev1, l.stream);
     if (!hip_ok(hipGetLastError(), "kernel launch") || !hip_ok(hipStreamSynchronize(l.stream), "wavefront render")) return RT1W_ERR_DEVICE;
@@ -612,25 +640,6 @@ int render_common(rt1w_context* c, const rt1w_render_params* p, double* d_out, r
 
 extern "C" {
 
-uint32_t rt1w_default_chunk(uint32_t tile_w, uint32_t tile_h, uint32_t spp) {
-    /* Work item = (pixel, chunk of samples).  The persistent kernel's tail is about half an item long, so:
-     *  - aim for >= ~16M items (>= 80 per resident lane; measured on C3: 4M items 1764, 16M items 1790 Mpaths/s),
-     *  - never more than 512 samples in an item (big frames at 10k spp: a whole pixel would be seconds of tail),
-     *  - never split below 8 samples, and keep the chunk partial sums (24 B per item) under 8 GiB. */
-    const uint64_t target_items = 16u << 20;
-    uint64_t pixels = (uint64_t)tile_w * tile_h;
-    if (pixels == 0 || spp == 0) return 1;
-    uint64_t n_chunks = (target_items + pixels - 1) / pixels;
-    const uint64_t by_len = ((uint64_t)spp + 511u) / 512u;
-    if (n_chunks < by_len) n_chunks = by_len;
-    const uint64_t by_mem = ((8ull << 30) / 24u) / pixels;
-    if (n_chunks > by_mem) n_chunks = by_mem;
-    if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > spp) n_chunks = spp;
-    uint32_t chunk = (uint32_t)((spp + n_chunks - 1) / n_chunks);
-    if (chunk < 8u) chunk = spp < 8u ? spp : 8u;
-    return chunk;
-}
 
 int rt1w_device_count(void) {
     int n = 0;
@@ -834,7 +843,7 @@ int rt1w_render_rows(rt1w_context* c, const rt1w_render_params* p, uint32_t stri
     if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return RT1W_ERR_DEVICE;
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t H = p->tile_h, W = p->tile_w;
-    const uint32_t tile_chunk = p->chunk ? p->chunk : rt1w_default_chunk(W, H, p->spp); /* the whole tile's chunking */
+    const uint32_t tile_chunk = p->chunk ? p->chunk : ((c->variant >= 2) ? 1u : rt1w_default_chunk(W, H, p->spp)); /* the whole tile's chunking (rt1w_scene_default_chunk) */
     if (strip_rows == 0) {
         /* about 16 strips, but never so thin that a strip has fewer than ~4M work items (pixel x sample chunk): the
          * persistent kernel needs that many to keep its tail short, and the chunking is the whole tile's by contract */

@@ -700,7 +700,16 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
         if (lane == 0u) cnt[wave][RT_SS_KEYS] = (uint32_t)__popcll(free_m);
         RT_STAMP(8);
         __syncthreads();
+#ifdef RT_STAMPS
+        { /* diagnostic builds: the first barrier's wait by why this wave left its slice -- 9: the workgroup's count was reached, 12: the
+             wave's own walks ran out first, 13: the wave had no walk to begin with */
+            const uint32_t left_ = (uint32_t)__popcll(__ballot(walking));
+            const uint32_t had_ = (uint32_t)__popcll(__ballot(!retired));
+            RT_STAMP(had_ == 0u ? 13 : (left_ == 0u ? 12 : 9));
+        }
+#else
         RT_STAMP(9);
+#endif
         if constexpr (RT_SS_WG_SLICE) { /* the next slice's counter: nobody touches it before the barriers below */
             if (threadIdx.x == 0u) __hip_atomic_store(&ss_done[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #if !RT_SS_ATOMIC_COUNTER

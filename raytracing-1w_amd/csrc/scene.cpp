@@ -943,6 +943,32 @@ int rt1w_scene_get_info(const rt1w_scene* s, rt1w_scene_info* out) {
     return RT1W_OK;
 }
 
+uint32_t rt1w_default_chunk(uint32_t tile_w, uint32_t tile_h, uint32_t spp) {
+    /* Work item = (pixel, chunk of samples).  The persistent kernel's tail is about half an item long, so:
+     *  - aim for >= ~16M items (>= 80 per resident lane; measured on C3: 4M items 1764, 16M items 1790 Mpaths/s),
+     *  - never more than 512 samples in an item (big frames at 10k spp: a whole pixel would be seconds of tail),
+     *  - never split below 8 samples, and keep the chunk partial sums (24 B per item) under 8 GiB. */
+    const uint64_t target_items = 16u << 20;
+    uint64_t pixels = (uint64_t)tile_w * tile_h;
+    if (pixels == 0 || spp == 0) return 1;
+    uint64_t n_chunks = (target_items + pixels - 1) / pixels;
+    const uint64_t by_len = ((uint64_t)spp + 511u) / 512u;
+    if (n_chunks < by_len) n_chunks = by_len;
+    const uint64_t by_mem = ((8ull << 30) / 24u) / pixels;
+    if (n_chunks > by_mem) n_chunks = by_mem;
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > spp) n_chunks = spp;
+    uint32_t chunk = (uint32_t)((spp + n_chunks - 1) / n_chunks);
+    if (chunk < 8u) chunk = spp < 8u ? spp : 8u;
+    return chunk;
+}
+
+uint32_t rt1w_scene_default_chunk(const rt1w_scene* s, uint32_t tile_w, uint32_t tile_h, uint32_t spp) {
+    if (!s || !s->committed) return 0u;
+    const int variant = rt_pick_variant((uint32_t)s->flat_nodes.size(), s->has_media, s->has_tex, s->has_msphere, s->scope_depth, s->walk_annotated != 0u);
+    return variant >= 2 ? 1u : rt1w_default_chunk(tile_w, tile_h, spp);
+}
+
 int64_t rt1w_scene_copy_flat(const rt1w_scene* s, int what, void* buf, uint64_t cap) {
     if (!s) { set_error("null scene"); return RT1W_ERR_INVALID; }
     if (!s->committed) { set_error("scene not committed"); return RT1W_ERR_STATE; }

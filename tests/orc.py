@@ -187,7 +187,7 @@ def flat_render(scene, width, height, spp, max_depth=50, tile=None, sample_offse
     `variant`: kernel variant (0..3, see rt_flat.h); default = the one the library picks."""
     x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
     if chunk == 0:
-        chunk = rt().default_chunk(tw, th, spp)
+        chunk = scene.default_chunk(tw, th, spp)   # the scene's own default (1 sample per item on the stack-walk kernels)
     arrs = [scene.flat(i) for i in range(7)]
     arrs[0] = np.concatenate([arrs[0], np.zeros(96, dtype=np.uint8)])   # one spare record: the fused walk reads record e + 1 with record e
     info = scene.info()

@@ -523,7 +523,7 @@ def test_interleaved_strips_and_shared_host_frame(rt, gpu_ctx_factory):
     sc = rt.Scene.reference(5, build_seed=1)
     ctx = gpu_ctx_factory(sc)
     W, H, spp = 96, 88, 8                      # 88 rows: five full 16-row strips and a ragged one
-    chunk = rt.default_chunk(W, H, spp)
+    chunk = sc.default_chunk(W, H, spp)
     full, _ = ctx.render(W, H, spp, chunk=chunk)
     for world in (1, 2, 3, 8):
         frame = rt.pinned_empty((H, W, 3))
@@ -576,7 +576,7 @@ def test_c5_full_size_3840x2160_10000spp(rt, gpu_ctx_factory):
     full, st = ctx.render_rows(W, H, spp, progress=lambda d, t: seen.append((d, t)) and False)
     assert st["paths"] == W * H * spp and seen and seen[-1] == (H, H)
     assert np.isfinite(full).all() and 3.0 < st["segments"] / st["paths"] < 3.6
-    chunk = rt.default_chunk(W, H, spp)
+    chunk = sc.default_chunk(W, H, spp)
     for tile in ((1916, 1080, 4, 2), (8, 8, 2, 2)):
         b, sb = orc.flat_render(sc, W, H, spp, tile=tile, chunk=chunk)
         x0, y0, w, h = tile
@@ -605,7 +605,7 @@ def test_c4_full_size_800x800_10000spp(rt, gpu_ctx_factory):
     final_png_block_check(full, 0.11, 0.02)
     final_png_disc_check(full, 0.08, "C4 full size: ")     # the literal objects (earth, moving sphere, blue ball): tighter than the blocks
     tile = (392, 300, 4, 2)
-    b, sb = orc.flat_render(sc, W, H, spp, tile=tile, chunk=rt.default_chunk(W, H, spp))
+    b, sb = orc.flat_render(sc, W, H, spp, tile=tile, chunk=sc.default_chunk(W, H, spp))
     assert np.array_equal(full[300:302, 392:396], b, equal_nan=True)
     literal_crop_check(7, None, W, H, spp, tile, full[300:302, 392:396], sb["segments"])
     print(f"C4 full size: {st['total_ms'] / 1e3:.1f} s, {st['paths'] / st['total_ms'] / 1e3:.0f} Mpaths/s incl. D2H")
@@ -757,7 +757,7 @@ def test_pair_walk_of_sphere_scenes_is_bit_identical(rt, gpu_ctx_factory):
             b, sb = ctx.render(W, H, spp, classic_walk=True)
             assert sa["sorted"] & 128 and not (sb["sorted"] & 128), (sa["sorted"], sb["sorted"])
             assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, W, H, spp)
-        cpu, sc_ = orc.flat_render(sc, 96, 64, 8, chunk=rt.default_chunk(96, 64, 8))
+        cpu, sc_ = orc.flat_render(sc, 96, 64, 8, chunk=sc.default_chunk(96, 64, 8))
         a, sa = ctx.render(96, 64, 8)
         assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), sah
         ctx.close()
@@ -793,7 +793,7 @@ def test_sphere_media_kernels_are_bit_identical(rt, gpu_ctx_factory):
             assert sa["sorted"] & 256 and not (sb["sorted"] & 256), (sa["sorted"], sb["sorted"])
             assert sa["variant"] == sb["variant"] == (4 if near_far else 3)
             assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, near_far, W, H, spp)
-        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=rt.default_chunk(64, 64, 6))
+        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=sc.default_chunk(64, 64, 6))
         a, sa = ctx.render(64, 64, 6)
         assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), (sah, near_far)
         ctx.close()
@@ -802,7 +802,7 @@ def test_sphere_media_kernels_are_bit_identical(rt, gpu_ctx_factory):
     ctx = gpu_ctx_factory(sc)
     a, sa = ctx.render(48, 48, 4, variant=3)
     assert sa["variant"] == 3 and not (sa["sorted"] & 256)
-    cpu, sc_ = orc.flat_render(sc, 48, 48, 4, chunk=rt.default_chunk(48, 48, 4))
+    cpu, sc_ = orc.flat_render(sc, 48, 48, 4, chunk=sc.default_chunk(48, 48, 4))
     assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True)
     ctx.close()
 
@@ -827,7 +827,7 @@ def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
             assert sa["sorted"] & 512 and sa["sorted"] & 256 and not (sb["sorted"] & 512) and sb["sorted"] & 256, (sa["sorted"], sb["sorted"])
             assert sa["variant"] == sb["variant"] == (4 if near_far else 3)
             assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (sah, near_far, W, H, spp, kw)
-        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=rt.default_chunk(64, 64, 6))
+        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=sc.default_chunk(64, 64, 6))
         a, sa = ctx.render(64, 64, 6)
         assert sa["sorted"] & 512 and sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), (sah, near_far)
         ctx.close()
@@ -846,7 +846,7 @@ def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
                 c_, sc2 = ctx.render(W, H, spp, **kw, **kw2)
                 assert sc2["sorted"] & 512 and not (sc2["sorted"] & 128), (kw2, sc2["sorted"])
                 assert sc2["segments"] == sb["segments"] and np.array_equal(c_, b, equal_nan=True), (sah, W, H, spp, kw, kw2)
-        cpu, sc_ = orc.flat_render(sc, 96, 64, 6, chunk=rt.default_chunk(96, 64, 6))
+        cpu, sc_ = orc.flat_render(sc, 96, 64, 6, chunk=sc.default_chunk(96, 64, 6))
         a, sa = ctx.render(96, 64, 6)
         assert sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), sah
         ctx.close()
@@ -865,7 +865,7 @@ def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
     for sc, W, H, spp in cases:
         info = sc.info()
         ctx = gpu_ctx_factory(sc)
-        cpu, sc_ = orc.flat_render(sc, W, H, spp, chunk=rt.default_chunk(W, H, spp))
+        cpu, sc_ = orc.flat_render(sc, W, H, spp, chunk=sc.default_chunk(W, H, spp))
         for v in [3] + ([2] if not info["has_media"] else []) + ([5] if (not info["has_media"] and info["scope_depth"] == 0) else []):
             a, sa = ctx.render(W, H, spp, variant=v)
             b, sb = ctx.render(W, H, spp, variant=v, unsorted=True)
@@ -888,3 +888,35 @@ def test_precompiled_kernels_load_on_a_host_without_the_runtime_compiler(rt):
     env = dict(os.environ, RT1W_NO_HIPRTC="1", RT1W_KERNEL_CACHE="/nonexistent-rt1w-cache")
     out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
     assert out == ["1", "1", "4"], out
+
+
+def test_one_sample_per_work_item_and_sample_passes(rt, gpu_ctx_factory):
+    """Scenes on the stack-walk kernels render with ONE sample per work item by default (rt1w_scene_default_chunk: free lanes of a wave restart
+    together on neighbouring pixels; the pixel sum is the reference's own sequential sum, main.rs:966-992), and a render whose chunk partial
+    sums would not fit the budget (default 8 GiB; here `partial_mib` makes it a few MiB) runs as several passes over sample ranges.  What
+    must hold: the default chunk is 1 and the frame equals the CPU build of the core with chunk 1 bit for bit; the same frame whatever the
+    budget (1 pass, 3 passes, a pass per sample) incl. a ragged last pass, raw sums (RT1W_OUT_SUM), a sample offset and a tile; the small
+    scenes keep the scene-independent rule; equal segment counts throughout."""
+    for arm, aspect, W, H, spp in ((0, 1.5, 96, 64, 10), (7, None, 64, 64, 7)):
+        sc = rt.Scene.reference(arm, build_seed=1, aspect_ratio=aspect)
+        assert sc.default_chunk(W, H, spp) == 1 and sc.default_chunk(1200, 800, 500) == 1
+        ctx = gpu_ctx_factory(sc)
+        full, st = ctx.render(W, H, spp)
+        assert st["chunk"] == 1 and st["n_chunks"] == spp
+        cpu, sc_ = orc.flat_render(sc, W, H, spp, chunk=1)
+        assert st["segments"] == sc_["segments"] and np.array_equal(full, cpu, equal_nan=True), arm
+        per_sample_mib = W * H * 24 / 2 ** 20
+        for mib in (max(1, int(4 * per_sample_mib)), max(1, int(per_sample_mib * 1.01) + 0)):     # ~3 passes (ragged), ~one pass per sample
+            got, sg = ctx.render(W, H, spp, partial_mib=mib)
+            assert sg["segments"] == st["segments"] and sg["n_chunks"] == spp and np.array_equal(got, full, equal_nan=True), (arm, mib)
+        raw, sr = ctx.render(W, H, spp, out_sum=True, partial_mib=1)
+        assert np.array_equal(rt.resolve(raw, spp), full, equal_nan=True), arm
+        off, so = ctx.render(W, H, 4, sample_offset=3, tile=(8, 16, 32, 24), partial_mib=1)
+        cpu_off, _ = orc.flat_render(sc, W, H, 4, sample_offset=3, tile=(8, 16, 32, 24), chunk=1)
+        assert np.array_equal(off, cpu_off, equal_nan=True), arm
+        three, s3 = ctx.render(W, H, spp, chunk=3, partial_mib=1)                                   # explicit chunks also run in passes
+        cpu3, _ = orc.flat_render(sc, W, H, spp, chunk=3)
+        assert s3["chunk"] == 3 and np.array_equal(three, cpu3, equal_nan=True), arm
+        ctx.close()
+    small = rt.Scene.reference(5, build_seed=1)
+    assert small.default_chunk(600, 600, 1000) == rt.default_chunk(600, 600, 1000) > 1

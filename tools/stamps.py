@@ -16,7 +16,7 @@ else:
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc
 rt = orc.rt()
-names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+tail", "loop top", "exchange: read", "sort: ballots+counts", "sort: barrier 1 wait", "exchange: rank+write", "exchange: barrier 2 wait", "-", "-", "-", "-"]
+names = ["-", "regen", "traverse", "hit record", "shade lambert", "shade other+tail", "loop top", "exchange: read", "sort: ballots+counts", "sort: barrier 1 wait", "exchange: rank+write", "exchange: barrier 2 wait", "barrier 1 wait: own walks ran out (ss kernels)", "barrier 1 wait: no walk at all (ss kernels)", "-", "-"]
 if walk:
     names[8:14] = ["walk: pop + fetch + class", "walk: box", "walk: leaf", "walk: wrapper entry", "walk: wrapper exit", "walk: medium (outside its boundary walks)"]
     names[2] = "walk: loop control, slice votes"
