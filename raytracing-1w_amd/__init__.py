@@ -376,7 +376,7 @@ class Context:
 
     @staticmethod
     def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False,
-                strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False, probe_coherent=False):
+                strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False, probe_coherent=False, partial_mib=0):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
         if wavefront:
             load_lab()
