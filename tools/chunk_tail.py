@@ -1,4 +1,4 @@
-"""Work-item size (samples per item, rt1w_render_params.chunk) against the persistent kernel's tail on the big scenes: the last items
+"""Work-item size (samples per item, rt1w_render_params.chunk) on the big scenes: the last items
 started keep a few lanes busy while the rest of the GPU has retired, and an item of a stack-walk scene is long (final_scene: ~110 us per
 segment and lane).  kernel ms and Mpaths/s per chunk;  python3 tools/chunk_tail.py [arm] [W] [H] [spp] [chunks...]"""
 import importlib, os, sys
