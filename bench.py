@@ -241,6 +241,14 @@ def cpu_baseline(wl, width, height):
                               "sample": f"{spp_one} spp ({paths_one} paths in {dt_one:.1f} s)"}}
 
 
+def sample_passes(npix, n_chunks, partial_mib=0):
+    """launches of the render kernel per render: a render whose chunk partial sums (24 B per pixel and chunk) exceed the budget (8 GiB unless
+    rt1w_render_params.partial_mib says otherwise) runs as several passes over sample ranges (csrc/context.hip: chunks_per_pass)"""
+    budget = (partial_mib << 20) if partial_mib else (8 << 30)
+    cpp = max(1, min(n_chunks, budget // max(1, npix * 24)))
+    return (n_chunks + cpp - 1) // cpp
+
+
 def git_head():
     """commit of the tree: `git rev-parse` where there is a repository, else the VERSION file build() wrote (the GPU box
     receives the tree without .git)"""
@@ -382,6 +390,7 @@ def measure_single(be, dev, key, spp, steps, warmup, bvh, walk_order, generic=Fa
            "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 3),
            "value_kernel_only": round(paths / kernel_ms / 1e3, 2),
            "paths_per_step": paths, "segments_per_path": round(st["segments"] / paths, 4),
+           "samples_per_work_item": st["chunk"], "sample_passes": sample_passes(W * H, st["n_chunks"]),
            "scene_nodes": scene.info()["n_nodes"], "bvh": bvh_label(bvh, walk_order), "dtype": "f64",
            "roofline": roofline_block(key if (bvh == DEFAULT_BVH and walk_order == "reference") else None, st, kernel_ms, W * H,
                                       spec.get("key") if spec else None, spp)}
@@ -616,7 +625,8 @@ def rank_main(a, be=None):
                                        f"timed region = kernels + device->host gather into one pinned host frame",
                            "width": W, "height": H, "spp": spp, "max_depth": DEPTH,
                            "paths_per_step": paths_per_step, "segments_per_path": round(seg_total / paths_per_step, 4),
-                           "chunk": st["chunk"], "n_chunks": st["n_chunks"], "grid": st["grid"], "block": st["block"],
+                           "chunk": st["chunk"], "n_chunks": st["n_chunks"], "sample_passes": sample_passes(my_pixels, st["n_chunks"]),
+                           "grid": st["grid"], "block": st["block"],
                            "kernel_variant": st["variant"], "workgroup_path_sort": bool(flags & 1),
                            "scene_specialised_kernel": bool(flags & 4), "specialise": spec,
                            "scene_nodes": scene.info()["n_nodes"], "bvh": bvh_label(a.bvh, a.walk_order),

@@ -46,18 +46,22 @@ for wl, spp in (("c3", 1000), ("c2", 500), ("c4", 400)):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"])); names[k] += 1
     if not agg:
         continue
-    m = {k: sum(v) / len(v) for k, v in agg.items()}
     line = {}
     for l in open(OUT + "/%s.p1.log" % wl):
         if l.startswith("{"):
             line = json.loads(l)
+    # counters PER RENDER: the mean over the kernel's launches x the launches one render takes (sample passes, bench.py: config.sample_passes)
+    passes = line.get("config", {}).get("sample_passes", 1) or 1
+    m = {k: sum(v) / len(v) * (passes if not k.startswith("GRBM") else passes) for k, v in agg.items()}
+    ppasses = pline.get("config", {}).get("sample_passes", 1) or 1
+    pm = {k: v * ppasses for k, v in pm.items()}
     kern = line.get("roofline", {}).get("kernel")
     cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
     busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)  # 256 CUs x 4 SIMDs
     lanes = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])
     fetch_kb, write_kb = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
     out[wl] = {"kernel": kern, "specialise_key": (line.get("config", {}).get("specialise") or {}).get("key") if kern == "rt_jit_sorted" else None,
-               "spp_of_the_traffic_figure": spp, "commit": line.get("config", {}).get("commit"),
+               "spp_of_the_traffic_figure": spp, "sample_passes": passes, "commit": line.get("config", {}).get("commit"),
                "kernel_sources": line.get("config", {}).get("kernel_sources"),
                "segments_counted": line.get("config", {}).get("segments_counted"),
                "coherent_probe": ({"SQ_INSTS_VALU_per_launch": pm["SQ_INSTS_VALU"], "SQ_INSTS_SALU_per_launch": pm.get("SQ_INSTS_SALU"),
@@ -71,7 +75,7 @@ for wl, spp in (("c3", 1000), ("c2", 500), ("c4", 400)):
                "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
                "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024.0),
                "correction": "gfx950: FETCH_SIZE tallies 64 B per 128-B request on wide coalesced reads, so it is doubled; WRITE_SIZE as is (MI355X_MICROARCH.md)",
-               "source": "tools/bench_pmc.sh: rocprofv3 --pmc passes over bench.py --workload %s%s --steps 2 --warmup 0, means per launch of the dominant kernel" % (wl, " --spp 400" if wl == "c4" else ""),
+               "source": "tools/bench_pmc.sh: rocprofv3 --pmc passes over bench.py --workload %s%s --steps 2 --warmup 0, means per launch of the dominant kernel x the launches of one render (sample passes): per-render figures" % (wl, " --spp 400" if wl == "c4" else ""),
                "kernel_names_seen": list(names)[:2]}
 json.dump(out, open(OUT + "/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
