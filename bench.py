@@ -264,7 +264,7 @@ def git_head():
 
 KERNEL_SOURCES = ("include/rt1w_num.h", "raytracing-1w_amd/csrc/rt_flat.h", "raytracing-1w_amd/csrc/rt_core.h",
                   "raytracing-1w_amd/csrc/rt_kernel_sorted.h", "raytracing-1w_amd/csrc/rt_kernel_plain.h",
-                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/context.hip")
+                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/rt_kernels.h")
 
 
 def kernel_sources_id():
