@@ -264,7 +264,7 @@ def git_head():
 
 KERNEL_SOURCES = ("include/rt1w_num.h", "raytracing-1w_amd/csrc/rt_flat.h", "raytracing-1w_amd/csrc/rt_core.h",
                   "raytracing-1w_amd/csrc/rt_kernel_sorted.h", "raytracing-1w_amd/csrc/rt_kernel_plain.h",
-                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/rt_kernels.h")
+                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/rt_kernels.h", "raytracing-1w_amd/csrc/rt_walk_table.h")
 
 
 def kernel_sources_id():
@@ -326,7 +326,8 @@ def kernel_name(st):
     if flags & 128:
         return ("rt_render_kernel_pw_ss<V%d>" if (flags & 512) else "rt_render_kernel_pw<V%d>") % st["variant"]
     if flags & 512:
-        return ("rt_render_kernel_ss<V%d, sphere media>" if (flags & 256) else "rt_render_kernel_ss<V%d>") % st["variant"]
+        base = "rt_render_kernel_ss_hc" if (flags & 1024) else "rt_render_kernel_ss" # _hc: most visited node records in LDS (rt_walk_table.h)
+        return (base + ("<V%d, sphere media>" if (flags & 256) else "<V%d>")) % st["variant"]
     if flags & 256:
         return "rt_render_kernel<V%d, sphere media>" % st["variant"]
     return ("rt_render_kernel_sorted<V%d>" if (flags & 1) else "rt_render_kernel<V%d>") % st["variant"]

@@ -203,6 +203,7 @@ void rt1w_context_destroy(rt1w_context* c);
 #define RT1W_RNG_REFERENCE 64u /* PARITY MODE: draw from the reference's own generator instead of the Philox streams -- `StdRng::seed_from_u64(j * image_width + i)` (src/main.rs:964; ChaCha12, rand 0.8.4), one stream per pixel drawn on through all its samples in order (sample_offset must be 0, global_seed is ignored).  The frame is then the Rust program's own, pixel for pixel: the GPU reproduces rest_of_your_life.png.  Slower than the default (a lane owns a pixel for all its samples) */
 #define RT1W_CLASSIC_WALK 128u /* tests/ablation: sphere scenes (random_scene) walk their BVH with the pair walk of csrc/rt_walk_pair.h by default (box work and leaf work in separate phases, inner boxes in f32 rounded outward, every sphere gated by its group's own f64 box at the reference's moment: the same frames bit for bit, stats.sorted bit 7 says it ran); this flag keeps the one-entry-per-step walk.  Likewise scenes whose every ConstantMedium is bounded by a bare Sphere (final_scene) run stack-walk kernels built without the general boundary walks (rt_flat.h: RtCfgSphereMedia; stats.sorted bit 8); this flag keeps the general kernels */
 #define RT1W_PROBE_COHERENT 0x40000000u /* MEASUREMENT ONLY -- the frame written is NOT the image: every wave's 64 lanes trace the SAME path (one pixel of every 8x8 block, each 64 times), so the kernel runs without divergence and its instruction count per traced segment (rocprofv3 SQ_INSTS_VALU x 64 / stats.segments) is what ONE path needs in this kernel's code: the `necessary` side of bench.py's `roofline.valu` (tools/bench_pmc.sh).  Replaces nothing of the reference: a property of this implementation's measurement */
+#define RT1W_NO_NODE_CACHE 0x10000u /* tests/ablation: big scenes' stack-walk kernels keep the most visited node records in LDS (csrc/rt_walk_table.h: ranked by a visit count at context creation; stats.sorted bit 10 says the cache ran; same frames bit for bit); this flag keeps the kernels that read every record from memory */
 #define RT1W_UNSORTED 2u  /* tests/ablation: use the plain persistent kernel (no workgroup-level path reordering: neither the reordering kernel of the small scenes nor, for sphere-media scenes such as final_scene, the reordering of the finished paths at the end of every slice of the stack walk, stats.sorted bit 9) */
 #define RT1W_FORCE_VARIANT(v) ((((uint32_t)(v)) + 1u) << 8) /* tests: force kernel variant v (must be valid for the scene) */
 
@@ -245,7 +246,7 @@ typedef struct rt1w_stats {
     uint32_t sorted;       /* bit 0: the reordering kernel ran; bit 1: node records in LDS; bit 2: scene-specialised kernel; bit 3:
                               wavefront form; bit 4: reference-stream kernel (RT1W_RNG_REFERENCE); bit 5: f32 kernel; bit 7: pair walk
                               (sphere scenes); bit 8: sphere-media build of the stack walk; bit 9: finished paths reordered across the
-                              workgroup at the end of every slice of the stack walk */
+                              workgroup at the end of every slice of the stack walk; bit 10: most visited node records in LDS (walk table) */
 } rt1w_stats;
 
 /* default work-item size for a (tile, spp): deterministic, documented in DESIGN.md.  This is the scene-independent rule (what the

@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "rt_core.h"
+#include "rt_walk_table.h" /* the walk table of the kernels that keep the most visited nodes in LDS: built and walked here on the CPU */
 #if !defined(RT_RNG_REFSTREAM)
 #include "rt_walk_pair.h" /* the pair walk of sphere scenes: its lane functions are built here with bound-checked stacks and queues */
 #endif
@@ -170,6 +171,49 @@ void orcflat_rng_rewind_check(uint64_t seed, uint32_t pattern, uint32_t before, 
 }
 
 } /* extern "C" */
+
+/* The walk over the WALK TABLE (rt_walk_table.h; rt_core.h: RtWalkNodes) on the CPU, ray by ray, against the walk over the node array.
+ * `rays[n][8]` = origin, direction, time, unused; `visits` (n_nodes counts, may be NULL) ranks the table as the context's visit count
+ * does -- tests hand in arbitrary counts: whatever the ranking, every ray must report the same t, primitive and scope and leave the
+ * random stream (media draw inside the walk) in the same state.  `nc` = how many records the "cache" holds (the walk reads record v from
+ * one array below nc and from the other above: any value must do).  variant 3 = the general media walk, 103 = the sphere-media build.
+ * out_flags per ray: bit 0 the two walks differ, bit 1 a stack overflowed.  Returns 0, -1 if the table cannot be built. */
+extern "C" int orcflat_walk_table_check(const void* nodes_, uint32_t n_nodes, uint32_t root, const uint32_t* visits, uint32_t nc, int variant,
+                                        const double* rays, uint64_t n, double* out_t, uint32_t* out_prim, uint32_t* out_scope, uint32_t* out_flags,
+                                        uint32_t* id_of_out) {
+    const RtNode* nodes = (const RtNode*)nodes_;
+    std::vector<RtNode> N(nodes, nodes + n_nodes);
+    RtWalkTable T;
+    std::string why;
+    if (!rt_walk_table_build(N, root, visits, T, why)) return -1;
+    if (id_of_out) std::memcpy(id_of_out, T.id_of.data(), (size_t)n_nodes * 4u);
+    RtSceneView sc;
+    std::memset(&sc, 0, sizeof sc);
+    sc.nodes = nodes; sc.root = root; sc.n_nodes = n_nodes;
+    std::vector<RtNodeHot> head(T.rec.begin(), T.rec.begin() + (nc < n_nodes ? nc : n_nodes)); /* a separate copy, as the LDS is */
+    RtWalkNodes wn; wn.lds = head.data(); wn.glob = T.rec.data(); wn.nc = (uint32_t)head.size();
+    RtGlobalNodes gn{nodes};
+    for (uint64_t i = 0; i < n; ++i) {
+        RtRay r;
+        r.o = rt_v3(rays[i * 8 + 0], rays[i * 8 + 1], rays[i * 8 + 2]); r.d = rt_v3(rays[i * 8 + 3], rays[i * 8 + 4], rays[i * 8 + 5]); r.time = rays[i * 8 + 6];
+        HostStack sa, sb;
+        RtRng ra = rt_rng_pixel_sample(i, 5u, 9u), rb = ra;
+        double ta = 0, tb = 0; uint32_t pa = RT_NONE, pb = RT_NONE, ca = RT_NONE, cb = RT_NONE;
+        bool ha, hb;
+        if (variant == 103) {
+            ha = rt_traverse_stack<RtCfgSphereMedia<RtCfgV3>, true>(sc, gn, root, r, RT_R(0.001), RT_INF, ra, sa, ta, pa, ca);
+            hb = rt_traverse_stack<RtCfgSphereMedia<RtCfgV3>, true>(sc, wn, 0u, r, RT_R(0.001), RT_INF, rb, sb, tb, pb, cb);
+        } else {
+            ha = rt_traverse_stack<RtCfgV3, true>(sc, gn, root, r, RT_R(0.001), RT_INF, ra, sa, ta, pa, ca);
+            hb = rt_traverse_stack<RtCfgV3, true>(sc, wn, 0u, r, RT_R(0.001), RT_INF, rb, sb, tb, pb, cb);
+        }
+        uint32_t fl = 0;
+        if (ha != hb || pa != pb || (ha && (std::memcmp(&ta, &tb, sizeof ta) != 0 || ca != cb)) || rt_next_u64(ra) != rt_next_u64(rb)) fl |= 1u;
+        if (sa.overflow || sb.overflow || sb.max_sp > sa.max_sp) fl |= 2u; /* the table's walk needs no more stack than the node array's */
+        out_t[i] = tb; out_prim[i] = hb ? pb : RT_NONE; out_scope[i] = hb ? cb : RT_NONE; out_flags[i] = fl;
+    }
+    return 0;
+}
 
 #if !defined(RT_RNG_REFSTREAM)
 namespace {

@@ -50,6 +50,7 @@ LDS_NODES = 4
 GENERIC = 8  # do not use a scene-specialised kernel for this render
 OUT_FRAME = 32  # rt1w_render: `out` is the whole image; only the tile's pixels are written, at their image positions
 RNG_REFERENCE = 64  # parity mode: the reference's own ChaCha12 stream per pixel (main.rs:964)
+NO_NODE_CACHE = 0x10000  # big scenes: the stack-walk kernels without the most visited node records in LDS (rt_walk_table.h)
 CLASSIC_WALK = 128  # sphere scenes: the one-entry-per-step walk instead of the pair walk (rt_walk_pair.h)
 WAVEFRONT = 16  # big scenes: path state queued in HBM, trace / shade kernels per bounce
 SPECIALISE_CACHED_ONLY = 1
@@ -376,11 +377,11 @@ class Context:
 
     @staticmethod
     def _params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False,
-                strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False, probe_coherent=False, partial_mib=0):
+                strips=None, out_frame=False, reference_stream=False, f32=False, classic_walk=False, probe_coherent=False, partial_mib=0, no_node_cache=False):
         x0, y0, tw, th = tile if tile is not None else (0, 0, width, height)
         if wavefront:
             load_lab()
-        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (CLASSIC_WALK if classic_walk else 0) | (PROBE_COHERENT if probe_coherent else 0) | (((variant + 1) << 8) if variant is not None else 0)
+        flags = (OUT_SUM if out_sum else 0) | (OUT_FRAME if out_frame else 0) | (RNG_REFERENCE if reference_stream else 0) | (UNSORTED if unsorted else 0) | (LDS_NODES if lds_nodes else 0) | (GENERIC if generic else 0) | (WAVEFRONT if wavefront else 0) | (CLASSIC_WALK if classic_walk else 0) | (NO_NODE_CACHE if no_node_cache else 0) | (PROBE_COHERENT if probe_coherent else 0) | (((variant + 1) << 8) if variant is not None else 0)
         sr, sp = strips if strips is not None else (0, 0)
         return RenderParams(width, height, x0, y0, tw, th, spp, sample_offset, max_depth, global_seed, chunk, flags, sr, sp, 1 if f32 else 0, int(partial_mib))
 
@@ -401,14 +402,14 @@ class Context:
 
     def render(self, width, height, spp, max_depth=50, tile=None, sample_offset=0, global_seed=0, chunk=0, out_sum=False,
                variant=None, unsorted=False, lds_nodes=False, generic=False, wavefront=False, strips=None, out=None, frame=None,
-               reference_stream=False, f32=False, classic_walk=False, probe_coherent=False, partial_mib=0):
+               reference_stream=False, f32=False, classic_walk=False, probe_coherent=False, partial_mib=0, no_node_cache=False):
         """Returns (image[tile_h, tile_w, 3] float64 with row 0 = reference row j = y0, stats dict).
         probe_coherent: measurement mode RT1W_PROBE_COHERENT -- the returned array is NOT the image.
         strips=(strip_rows, strip_period): row-interleaved tile (tile row r = image row y0 + r//strip_rows*strip_period +
         r%strip_rows).  out: caller's array for the packed tile (e.g. pinned_empty).  frame: caller's WHOLE image
         [height, width, 3]; the tile's pixels are written at their image positions (RT1W_OUT_FRAME) and `frame` is returned."""
         p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, variant, unsorted, lds_nodes, generic, wavefront,
-                         strips, frame is not None, reference_stream, f32, classic_walk, probe_coherent, partial_mib)
+                         strips, frame is not None, reference_stream, f32, classic_walk, probe_coherent, partial_mib, no_node_cache)
         if frame is not None:
             assert frame.dtype == np.float64 and frame.shape == (height, width, 3) and frame.flags.c_contiguous
             out = frame

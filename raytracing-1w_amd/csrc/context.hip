@@ -50,6 +50,7 @@ extern "C" int rt1w_internal_f32_launch(void* h, int variant, int sorted, const 
                                         hipStream_t stream);
 
 #include "rt_kernels.h"
+#include "rt_walk_table.h"
 
 namespace {
 
@@ -115,6 +116,8 @@ struct rt1w_context {
     int grid[RT_N_VARIANTS] = {};
     int grid_sphere_media[RT_N_VARIANTS] = {};
     int grid_ss[2][RT_N_VARIANTS] = {};
+    int grid_ss_hc[2][RT_N_VARIANTS] = {}; /* the same kernels with the node cache (rt_render_kernel_ss_hc); 0: this context has no walk table */
+    bool walk_table = false; uint32_t walk_table_first = 0;
     bool sphere_media = false; /* every medium of the scene is bounded by a bare Sphere: g_kernels_sphere_media serve */
     int grid_sorted[RT_N_VARIANTS] = {};
     int grid_cached[RT_N_VARIANTS] = {};
@@ -162,6 +165,10 @@ static render_kernel_t const g_kernels_sphere_media[RT_N_VARIANTS] = {nullptr, n
 static render_kernel_t const g_kernels_ss[2][RT_N_VARIANTS] = {
     {nullptr, nullptr, rt_render_kernel_ss<RtCfgV2, RT_SS_CAP, 3>, rt_render_kernel_ss<RtCfgV3, RT_SS_CAP, 3>, nullptr, rt_render_kernel_ss<RtCfgV5, RT_SS_CAP, 3>},
     {nullptr, nullptr, nullptr, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV3>, RT_SS_CAP, 3>, rt_render_kernel_ss<RtCfgSphereMedia<RtCfgV4>, RT_SS_CAP, 3>, nullptr}};
+/* ... and with the scene's most visited nodes in LDS (rt_walk_table.h): what a context with a walk table runs */
+static render_kernel_t const g_kernels_ss_hc[2][RT_N_VARIANTS] = {
+    {nullptr, nullptr, rt_render_kernel_ss_hc<RtCfgV2>, rt_render_kernel_ss_hc<RtCfgV3>, nullptr, rt_render_kernel_ss_hc<RtCfgV5>},
+    {nullptr, nullptr, nullptr, rt_render_kernel_ss_hc<RtCfgSphereMedia<RtCfgV3>>, rt_render_kernel_ss_hc<RtCfgSphereMedia<RtCfgV4>>, nullptr}};
 /* stack variants with the LDS node cache (scenes of <= RT_LDS_NODE_CAP nodes; opt-in: RT1W_LDS_NODES).  Measured on
  * random_scene: 464 Mpaths/s (80 KB LDS -> 2 waves/SIMD) against 486 for the plain variant at 3 waves/SIMD. */
 static render_kernel_t const g_kernels_cached[RT_N_VARIANTS] = {nullptr, nullptr, rt_render_kernel<RtCfgV2, true>, rt_render_kernel<RtCfgV3, true>, nullptr, rt_render_kernel<RtCfgV5, true>};
@@ -179,13 +186,44 @@ bool upload(void** dst, const void* src, size_t bytes) {
     return true;
 }
 
-/* the node array with one spare (zeroed) record behind it: the fused walk requests record e + 1 together with record e */
+/* the node array with one spare (zeroed) record behind it (the fused walk requests record e + 1 together with record e), and behind
+ * that, at RT_WT_OFFSET, room for the scene's walk table (rt_walk_table.h; written by build_walk_table once the visits are counted) */
 bool upload_nodes(void** dst, const std::vector<RtNode>& nodes) {
-    std::vector<RtNode> padded(nodes);
-    RtNode z;
-    memset(&z, 0, sizeof z);
-    padded.push_back(z);
-    return upload(dst, padded.data(), padded.size() * sizeof(RtNode));
+    const size_t n = nodes.size();
+    std::vector<unsigned char> buf(RT_WT_OFFSET(n) + n * sizeof(RtNodeHot), 0);
+    if (n) memcpy(buf.data(), nodes.data(), n * sizeof(RtNode));
+    return upload(dst, buf.data(), buf.size());
+}
+
+/* The walk table of a stack-walk scene (rt_walk_table.h), ranked by MEASURED visits: a 128 x 128 x 1 render of the scene's own camera
+ * with a kernel that counts the node fetches (rt_visit_count_kernel: a few ms, once per context).  Which nodes the kernels keep in LDS
+ * changes where a record is read from and nothing else -- a scene whose table cannot be built, or whose walk needs more stack than the
+ * cached kernels have, simply keeps the kernels without the cache. */
+bool build_walk_table(rt1w_context* c, const std::vector<RtNode>& nodes, uint32_t root, uint32_t stack_need, std::string& why) {
+    const uint32_t n = (uint32_t)nodes.size();
+    if (stack_need > (uint32_t)RT_SS_HC_CAP) { why = "the walk needs more than RT_SS_HC_CAP stack entries"; return false; }
+    uint32_t* d_visits = nullptr;
+    std::vector<uint32_t> visits(n, 0u);
+    if (!hip_ok(hipMalloc((void**)&d_visits, (size_t)n * 4u), "hipMalloc(visits)")) return false;
+    bool ok = hip_ok(hipMemset(d_visits, 0, (size_t)n * 4u), "hipMemset(visits)");
+    if (ok) {
+        RtFrame f;
+        memset(&f, 0, sizeof f);
+        f.width = f.tile_w = 128u; f.height = f.tile_h = 128u; f.spp = 1u; f.max_depth = 50u; f.chunk = 1u; f.n_chunks = 1u;
+        hipLaunchKernelGGL(rt_visit_count_kernel, dim3(64), dim3(256), 0, c->lane[0].stream, c->view, f, d_visits);
+        ok = hip_ok(hipGetLastError(), "rt_visit_count_kernel") &&
+             hip_ok(hipMemcpyAsync(visits.data(), d_visits, (size_t)n * 4u, hipMemcpyDeviceToHost, c->lane[0].stream), "hipMemcpy(visits)") &&
+             hip_ok(hipStreamSynchronize(c->lane[0].stream), "hipStreamSynchronize(visits)");
+    }
+    (void)hipFree(d_visits);
+    if (!ok) { why = "the visit count failed"; return false; }
+    RtWalkTable T;
+    if (!rt_walk_table_build(nodes, root, visits.data(), T, why)) return false;
+    if (!hip_ok(hipMemcpy((unsigned char*)c->d_nodes + RT_WT_OFFSET(n), T.rec.data(), (size_t)n * sizeof(RtNodeHot), hipMemcpyHostToDevice), "hipMemcpy(walk table)")) {
+        why = "upload failed"; return false;
+    }
+    c->walk_table_first = T.n_first;
+    return true;
 }
 
 /* RT1W_PRECISION_F32: the f32 copies of the scene arrays, at the first f32 render */
@@ -262,7 +300,7 @@ void lane_destroy(RtLane& l) {
 #ifndef RT_PARTIAL_BUDGET
 #define RT_PARTIAL_BUDGET (8ull << 30)
 #endif
-struct RtLaunch { RtFrame f; unsigned long long npix; unsigned long long partial_budget = RT_PARTIAL_BUDGET; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false, sphere_media = false, ss = false; };
+struct RtLaunch { RtFrame f; unsigned long long npix; unsigned long long partial_budget = RT_PARTIAL_BUDGET; int variant, grid, block; bool sorted, cached, jit, ref, f32, pw = false, sphere_media = false, ss = false, hc = false; };
 int specialise_f32(rt1w_context* c, bool allow_compile);
 
 /* what the launch will need, without launching: frame, variant, launch shape */
@@ -349,7 +387,8 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     L.cached = !L.sorted && g_kernels_cached[variant] != nullptr && c->n_nodes <= RT_LDS_NODE_CAP && (p->flags & RT1W_LDS_NODES);
     L.sphere_media = !L.sorted && !L.cached && c->sphere_media && g_kernels_sphere_media[variant] != nullptr && !(p->flags & RT1W_CLASSIC_WALK);
     L.ss = !L.sorted && !L.cached && g_kernels_ss[L.sphere_media ? 1 : 0][variant] != nullptr && !(p->flags & RT1W_UNSORTED);
-    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.ss ? c->grid_ss[L.sphere_media ? 1 : 0][variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant])));
+    L.hc = L.ss && c->walk_table && c->grid_ss_hc[L.sphere_media ? 1 : 0][variant] > 0 && !(p->flags & RT1W_NO_NODE_CACHE);
+    L.grid = L.sorted ? c->grid_sorted[variant] : (L.cached ? c->grid_cached[variant] : (L.hc ? c->grid_ss_hc[L.sphere_media ? 1 : 0][variant] : (L.ss ? c->grid_ss[L.sphere_media ? 1 : 0][variant] : (L.sphere_media ? c->grid_sphere_media[variant] : c->grid[variant]))));
     L.block = L.sorted ? RT_SORT_BLOCK : RT_BLOCK;
     return RT1W_OK;
 }
@@ -417,7 +456,7 @@ int render_launch(rt1w_context* c, RtLane& l, const rt1w_render_params* p, const
         if (L.ss) hipLaunchKernelGGL(rt_render_kernel_pw_ss<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, PF, l.d_partial, l.d_counters);
         else hipLaunchKernelGGL(rt_render_kernel_pw<RtCfgV5>, dim3(L.grid), dim3(L.block), 0, l.stream, c->view, c->pw, PF, l.d_partial, l.d_counters);
     } else {
-        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.ss ? g_kernels_ss[L.sphere_media ? 1 : 0][L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant]))),
+        hipLaunchKernelGGL(L.sorted ? g_kernels_sorted[L.variant] : (L.cached ? g_kernels_cached[L.variant] : (L.hc ? g_kernels_ss_hc[L.sphere_media ? 1 : 0][L.variant] : L.ss ? g_kernels_ss[L.sphere_media ? 1 : 0][L.variant] : (L.sphere_media ? g_kernels_sphere_media[L.variant] : g_kernels[L.variant]))),
                            dim3(L.grid), dim3(L.block), 0, l.stream, c->view, PF, l.d_partial, l.d_counters);
     }
     {
@@ -444,7 +483,7 @@ int render_finish(RtLane& l, const RtLaunch& L, rt1w_stats* stats) {
         stats->kernel_ms = ms;
         stats->chunk = L.f.chunk; stats->n_chunks = L.f.n_chunks;
         stats->grid = (uint32_t)L.grid; stats->block = (uint32_t)L.block;
-        stats->variant = (uint32_t)L.variant; stats->sorted = ((L.sorted && !L.ss) ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u) | (L.sphere_media ? 256u : 0u) | (L.ss ? 512u : 0u);
+        stats->variant = (uint32_t)L.variant; stats->sorted = ((L.sorted && !L.ss) ? 1u : 0u) | (L.cached ? 2u : 0u) | (L.jit ? 4u : 0u) | (L.ref ? 16u : 0u) | (L.f32 ? 32u : 0u) | (L.pw ? 128u : 0u) | (L.sphere_media ? 256u : 0u) | (L.ss ? 512u : 0u) | (L.hc ? 1024u : 0u);
     }
     return RT1W_OK;
 }
@@ -683,6 +722,23 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
             }
         }
     } else c->pw_why = "not a wrapper-free, media-free scene of more than 64 nodes, or its tree is deeper than the pair walk's stack";
+    if (c->variant >= 2) {
+        /* a stack-walk scene: its walk table and the kernels that keep the table's head in LDS (sphere scenes run the pair walk by
+         * default; the table serves their one-entry-per-step renders, RT1W_CLASSIC_WALK) */
+        std::string why;
+        c->walk_table = build_walk_table(c, s->flat_nodes, s->flat_root, s->stack_need, why);
+        if (c->walk_table) {
+            for (int sm = 0; sm < 2; ++sm)
+                for (int v = 0; v < RT_N_VARIANTS; ++v) {
+                    if (!g_kernels_ss_hc[sm][v]) continue;
+                    int per_cu = 0;
+                    if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, g_kernels_ss_hc[sm][v], RT_BLOCK, 0), "occupancy query")) {
+                        rt1w_context_destroy(c); return RT1W_ERR_DEVICE;
+                    }
+                    c->grid_ss_hc[sm][v] = prop.multiProcessorCount * (per_cu < 1 ? 1 : per_cu);
+                }
+        }
+    }
     /* the opt-in modes' own data (f32 scene arrays, the wavefront form's walk records) are built at their first use:
      * ensure_f32_scene; the wavefront form's in librt1w_lab.so */
     c->h_nodes = s->flat_nodes; c->h_lights = s->flat_lights; c->h_materials = s->materials; c->h_textures = s->textures; c->h_perlin = s->perlin;

@@ -371,16 +371,36 @@ RT_HD bool rt_prim_hot_sel_t(const RtNodeHot& nd, uint32_t kind, RtV3 o, RtV3 d,
  *    node i's hot words in registers for the whole kernel and node n is read with
  *    v_readlane -- the traversal then touches no memory at all. */
 struct RtGlobalNodes {
+    static constexpr bool virt = false;
     const RtNode* p;
     RT_HD RtNodeHot hot(uint32_t n) const { return *reinterpret_cast<const RtNodeHot*>(p + n); }
 };
+/*  - RtWalkNodes (stack-walk kernels with the node cache): records of the WALK TABLE (rt_walk_table.h), addressed by a walk id
+ *    instead of the node index -- the table lists the nodes most likely to be visited first, and its first `nc` records sit in
+ *    LDS.  `virt`: stack entries are walk ids; a record names its children / itself by the fields below instead of e + 1 / e. */
+struct RtWalkNodes {
+    static constexpr bool virt = true;
+    const RtNodeHot* lds;  /* records [0, nc) */
+    const RtNodeHot* glob; /* the whole table */
+    uint32_t nc;
+    RT_HD RtNodeHot hot(uint32_t v) const { return v < nc ? lds[v] : glob[v]; }
+};
+/* where the context keeps the walk table: behind the node array and its spare record, at the next 128-byte boundary */
+#define RT_WT_OFFSET(n_nodes) ((((size_t)(n_nodes) + 1u) * sizeof(RtNode) + 127u) & ~(size_t)127u)
+#define RT_WT_INLINE_SPHERE 0x1000u /* walk-table record of a ConstantMedium: its boundary is a bare Sphere, centre in d[1..3], radius in d[4] */
+/* what a record says about its neighbours.  Node arrays: the left / only child is the next node in pre-order and an entry IS the node
+ * index.  Walk table: BVH node: skip = left / only child's walk id, b = right child's; wrapper: skip = child's walk id, mat = own node
+ * index; leaf and medium: skip = own node index (medium: mat = walk id of the boundary's root) */
+template <class NS> RT_HD uint32_t rt_ns_child(uint32_t e, const RtNodeHot& nd) { if constexpr (NS::virt) return nd.skip; else return e + 1u; }
+template <class NS> RT_HD uint32_t rt_ns_leaf_id(uint32_t e, const RtNodeHot& nd) { if constexpr (NS::virt) return nd.skip; else return e; }
+template <class NS> RT_HD uint32_t rt_ns_wrap_id(uint32_t e, const RtNodeHot& nd) { if constexpr (NS::virt) return nd.mat; else return e; }
 
 /* ----------------------------------------------------------- traversal -- */
 
 RT_HD RtV3 rt_inv3(RtV3 d) { return rt_v3(RT_R(1.0) / d.x, RT_R(1.0) / d.y, RT_R(1.0) / d.z); }
 
 /* ConstantMedium::hit constant_medium.rs:58-113, given the two boundary roots t1, t2 */
-RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_min, double t_max, RtRng& rng,
+RT_HD bool rt_medium_t(double neg_inv_density, RtV3 d, double t1, double t2, double t_min, double t_max, RtRng& rng,
                        double& t_out) {
     double rec1 = rt_max(t1, t_min);
     double rec2 = rt_min(t2, t_max);
@@ -389,10 +409,13 @@ RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_
     double ray_length = rt_mag(d);
     double distance_inside_boundary = (rec2 - rec1) * ray_length;
     rt_rng_reserve(rng, rt_rng_need_u64(rng));
-    double hit_distance = nd.d[0] * rt_log(rt_take_f64(rng));
+    double hit_distance = neg_inv_density * rt_log(rt_take_f64(rng));
     if (hit_distance > distance_inside_boundary) return false;
     t_out = rec1 + hit_distance / ray_length;
     return true;
+}
+RT_HD bool rt_medium_t(const RtNode& nd, RtV3 d, double t1, double t2, double t_min, double t_max, RtRng& rng, double& t_out) {
+    return rt_medium_t(nd.d[0], d, t1, t2, t_min, t_max, rng, t_out);
 }
 
 /* Closest hit of a subtree for a ray within [t_min, t_max], with an explicit per-lane stack (LDS
@@ -458,8 +481,9 @@ RT_HD void rt_walk_exit(const RtSceneView& sc, RtWalk& k, uint32_t e) {
 #ifndef RT_BRANCHLESS_PUSH
 #define RT_BRANCHLESS_PUSH 1
 #endif
-template <class Cfg, bool EARLY, class Stack>
+template <class Cfg, bool EARLY, class NS = RtGlobalNodes, class Stack>
 RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
+    const uint32_t left = rt_ns_child<NS>(e, nd); /* the left / only child */
     bool hit;
     if (RT_WAVE_ANY(k.tmin_nan || rt_isnan(k.best_t))) hit = rt_aabb_hit(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
     else hit = rt_aabb_hit_fast<EARLY>(nd.d, k.cur.o, k.inv, k.t_min, k.best_t);
@@ -469,25 +493,25 @@ RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
          * A miss, or a BVHChild::One, leaves dead words above the top: the flattener counts TWO slots for every BVH node
          * (scene.cpp, Flattener::emit), so the footprint of the pokes is inside stack_need */
         const bool two = (nd.kind & RT_KIND_MASK) == RT_BVH2;
-        stk.poke(0, two ? nd.b : e + 1u); /* BVH2: the right child below the left one (bvh.rs:38-47); BVH1: its only child */
-        stk.poke(1, e + 1u);
+        stk.poke(0, two ? nd.b : left); /* BVH2: the right child below the left one (bvh.rs:38-47); BVH1: its only child */
+        stk.poke(1, left);
         stk.sp += hit ? (two ? 2 : 1) : 0;
         return;
     }
 #endif
     if (hit) {
         if ((nd.kind & RT_KIND_MASK) == RT_BVH2) {
-            uint32_t first = e + 1u, second = nd.b; /* left child = the next node in pre-order, then the right one: bvh.rs:38-47 */
+            uint32_t first = left, second = nd.b; /* left child (the next node in pre-order), then the right one: bvh.rs:38-47 */
             const uint32_t ord = Cfg::ordered ? (nd.kind >> RT_BVH_ORDER_SHIFT) & RT_BVH_ORDER_MASK : 0u;
             if (Cfg::ordered && ord != 0u) { /* opt-in near-far order (variant V4 only): the child on the ray's near side first */
                 const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
                 const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
-                if ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower)) { first = nd.b; second = e + 1u; }
+                if ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower)) { first = nd.b; second = left; }
             }
             stk.push(second);
             stk.push(first);
         } else {
-            stk.push(e + 1u); /* only child: the next node in pre-order */
+            stk.push(left); /* only child */
         }
     }
 }
@@ -497,8 +521,9 @@ RT_HD void rt_walk_box(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
 RT_HD bool rt_tie_ok(double t, uint32_t e, double best_t, uint32_t best_prim) {
     return !(t == best_t && best_prim != RT_NONE && e < best_prim);
 }
-template <class Cfg>
-RT_HD void rt_walk_leaf(const RtSceneView& sc, RtWalk& k, uint32_t e, const RtNodeHot& nd) {
+template <class Cfg, class NS = RtGlobalNodes>
+RT_HD void rt_walk_leaf(const RtSceneView& sc, RtWalk& k, uint32_t e_, const RtNodeHot& nd) {
+    const uint32_t e = rt_ns_leaf_id<NS>(e_, nd); /* the node index: what the walk reports */
     const uint32_t kind = nd.kind & RT_KIND_MASK;
     double t;
     bool hit;
@@ -506,37 +531,44 @@ RT_HD void rt_walk_leaf(const RtSceneView& sc, RtWalk& k, uint32_t e, const RtNo
     else hit = rt_prim_hot_sel_t(nd, kind, k.cur.o, k.cur.d, k.t_min, k.best_t, t);
     if (hit && (!Cfg::ordered || rt_tie_ok(t, e, k.best_t, k.best_prim))) { k.best_t = t; k.best_prim = e; k.best_scope = k.scope; }
 }
-template <class Stack>
-RT_HD void rt_walk_wrap(RtWalk& k, uint32_t e, const RtNodeHot& nd, Stack& stk) {
+template <class NS = RtGlobalNodes, class Stack>
+RT_HD void rt_walk_wrap(RtWalk& k, uint32_t e_, const RtNodeHot& nd, Stack& stk) {
     const uint32_t kind = nd.kind & RT_KIND_MASK;
+    const uint32_t e = rt_ns_wrap_id<NS>(e_, nd); /* scopes and exit entries are node indices in every form of the walk */
     stk.push(e | RT_POP_FLAG);
     k.scope = e;
     if (kind != RT_FLIP) {
         k.cur = rt_scope_in(nd, k.cur);
         if (kind == RT_ROTATE_Y) k.inv = rt_inv3(k.cur.d);
     }
-    stk.push(e + 1u);
+    stk.push(rt_ns_child<NS>(e_, nd));
 }
 template <class Cfg, bool MEDIA, class Stack, class NS>
-RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_t e, const RtNodeHot& nd, RtRng& rng, Stack& stk) {
+RT_HD void rt_walk_other(const RtSceneView& sc, const NS& ns, RtWalk& k, uint32_t e_, const RtNodeHot& nd, RtRng& rng, Stack& stk) {
     if (MEDIA && Cfg::media && (nd.kind & RT_KIND_MASK) == RT_MEDIUM) {
         /* ConstantMedium::hit constant_medium.rs:58-113: two complete boundary walks, then the free-flight draw */
+        const uint32_t e = rt_ns_leaf_id<NS>(e_, nd);
         RtRay br; br.o = k.cur.o; br.d = k.cur.d; br.time = k.time;
         double t1, t2, t; uint32_t p_, s_;
         bool both;
-        const RtNodeHot bn = ns.hot(e + 1u);
-        if ((bn.kind & RT_KIND_MASK) == RT_SPHERE) {
+        bool sphere; RtV3 c; double radius; uint32_t broot;
+        if constexpr (NS::virt) {
+            sphere = (nd.kind & RT_WT_INLINE_SPHERE) != 0u; c = rt_v3(nd.d[1], nd.d[2], nd.d[3]); radius = nd.d[4]; broot = nd.mat;
+        } else {
+            const RtNodeHot bn = ns.hot(e + 1u);
+            sphere = (bn.kind & RT_KIND_MASK) == RT_SPHERE; c = rt_v3(bn.d[0], bn.d[1], bn.d[2]); radius = bn.d[3]; broot = e + 1u;
+        }
+        if (sphere) {
             /* the boundary is a bare Sphere (every medium of the reference's scenes): its walk is one stack entry, one leaf
              * test -- run the two tests (sphere.rs:31-48 with (-inf, inf), then (t1 + 0.0001, inf)) without the walk around them */
-            const RtV3 c = rt_v3(bn.d[0], bn.d[1], bn.d[2]);
-            both = rt_sphere_root(c, bn.d[3], br.o, br.d, -RT_INF, RT_INF, t1) && rt_sphere_root(c, bn.d[3], br.o, br.d, t1 + RT_R(0.0001), RT_INF, t2);
+            both = rt_sphere_root(c, radius, br.o, br.d, -RT_INF, RT_INF, t1) && rt_sphere_root(c, radius, br.o, br.d, t1 + RT_R(0.0001), RT_INF, t2);
         } else if constexpr (Cfg::sphere_media) {
-            both = false; (void)p_; (void)s_; /* not reached: the host gives these kernels only scenes without such a medium (RtCfgSphereMedia) */
+            both = false; (void)p_; (void)s_; (void)broot; /* not reached: the host gives these kernels only scenes without such a medium (RtCfgSphereMedia) */
         } else {
-            both = rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_, &k.inv) &&
-                   rt_traverse_stack<Cfg, false>(sc, ns, e + 1u, br, t1 + RT_R(0.0001), RT_INF, rng, stk, t2, p_, s_, &k.inv);
+            both = rt_traverse_stack<Cfg, false>(sc, ns, broot, br, -RT_INF, RT_INF, rng, stk, t1, p_, s_, &k.inv) &&
+                   rt_traverse_stack<Cfg, false>(sc, ns, broot, br, t1 + RT_R(0.0001), RT_INF, rng, stk, t2, p_, s_, &k.inv);
         }
-        if (both && rt_medium_t(sc.nodes[e], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
+        if (both && rt_medium_t(nd.d[0], k.cur.d, t1, t2, k.t_min, k.best_t, rng, t)) {
             k.best_t = t; k.best_prim = e; k.best_scope = k.scope;
         }
     }
@@ -552,9 +584,9 @@ RT_HD void rt_walk_visit(const RtSceneView& sc, const NS& ns, RtWalk& k, RtRng& 
     const uint32_t km = nd.kind & RT_KIND_MASK;
     RT_STAT_VISIT(km);
     /* the kinds are numbered so that each class is a range: the most frequent one costs one compare */
-    if (km <= RT_BVH1) rt_walk_box<Cfg, false>(k, e, nd, stk); /* the slab test without early exits (they paid while media boundaries were walked) */
-    else if (km <= RT_YZ) rt_walk_leaf<Cfg>(sc, k, e, nd);
-    else if (Cfg::scope_depth > 0 && km <= RT_FLIP) rt_walk_wrap(k, e, nd, stk); /* scope_depth 0: the scene has no wrapper node */
+    if (km <= RT_BVH1) rt_walk_box<Cfg, false, NS>(k, e, nd, stk); /* the slab test without early exits (they paid while media boundaries were walked) */
+    else if (km <= RT_YZ) rt_walk_leaf<Cfg, NS>(sc, k, e, nd);
+    else if (Cfg::scope_depth > 0 && km <= RT_FLIP) rt_walk_wrap<NS>(k, e, nd, stk); /* scope_depth 0: the scene has no wrapper node */
     else if (Cfg::media) rt_walk_other<Cfg, MEDIA>(sc, ns, k, e, nd, rng, stk);
 }
 /* one stack entry */
@@ -576,7 +608,7 @@ RT_HD bool rt_walk_box_step(const NS& ns, RtWalk& k, Stack& stk) {
     bool taken = false;
     if (!(Cfg::scope_depth > 0 && (e & RT_POP_FLAG))) {
         const RtNodeHot nd = ns.hot(e);
-        if ((nd.kind & RT_KIND_MASK) <= RT_BVH1) { RT_STAT_VISIT(nd.kind & RT_KIND_MASK); rt_walk_box<Cfg, false>(k, e, nd, stk); taken = true; }
+        if ((nd.kind & RT_KIND_MASK) <= RT_BVH1) { RT_STAT_VISIT(nd.kind & RT_KIND_MASK); rt_walk_box<Cfg, false, NS>(k, e, nd, stk); taken = true; }
     }
     if (!taken) stk.sp += 1; /* the entry is still where it was */
     return taken;
@@ -591,9 +623,9 @@ RT_HD void rt_walk_light_step(const RtSceneView& sc, const NS& ns, RtWalk& k, St
     if (Cfg::scope_depth > 0 && (e & RT_POP_FLAG)) { rt_walk_exit(sc, k, e); return; }
     const RtNodeHot nd = ns.hot(e);
     const uint32_t km = nd.kind & RT_KIND_MASK;
-    if (km <= RT_BVH1) { RT_STAT_VISIT(km); rt_walk_box<Cfg, false>(k, e, nd, stk); }
-    else if (km <= RT_YZ) { RT_STAT_VISIT(km); rt_walk_leaf<Cfg>(sc, k, e, nd); }
-    else if (Cfg::scope_depth > 0 && km <= RT_FLIP) { RT_STAT_VISIT(km); rt_walk_wrap(k, e, nd, stk); }
+    if (km <= RT_BVH1) { RT_STAT_VISIT(km); rt_walk_box<Cfg, false, NS>(k, e, nd, stk); }
+    else if (km <= RT_YZ) { RT_STAT_VISIT(km); rt_walk_leaf<Cfg, NS>(sc, k, e, nd); }
+    else if (Cfg::scope_depth > 0 && km <= RT_FLIP) { RT_STAT_VISIT(km); rt_walk_wrap<NS>(k, e, nd, stk); }
     else stk.sp += 1;
 }
 
@@ -605,7 +637,7 @@ RT_HD bool rt_walk_prim_step(const RtSceneView& sc, const NS& ns, RtWalk& k, Sta
     if (!(Cfg::scope_depth > 0 && (e & RT_POP_FLAG))) {
         const RtNodeHot nd = ns.hot(e);
         const uint32_t km = nd.kind & RT_KIND_MASK;
-        if (km > RT_BVH1 && km <= RT_YZ) { RT_STAT_VISIT(km); rt_walk_leaf<Cfg>(sc, k, e, nd); taken = true; }
+        if (km > RT_BVH1 && km <= RT_YZ) { RT_STAT_VISIT(km); rt_walk_leaf<Cfg, NS>(sc, k, e, nd); taken = true; }
     }
     if (!taken) stk.sp += 1;
     return taken;
@@ -649,9 +681,9 @@ RT_HD bool rt_traverse_stack(const RtSceneView& sc, const NS& ns, uint32_t root,
                 const RtNodeHot nd = ns.hot(e);
                 const uint32_t cls = rt_walk_class(nd.kind & RT_KIND_MASK);
                 RT_STAT_VISIT(nd.kind & RT_KIND_MASK);
-                if (cls == RT_WK_BOX) rt_walk_box<Cfg, false>(k, e, nd, stk);
-                else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg>(sc, k, e, nd);
-                else if (cls == RT_WK_WRAP) rt_walk_wrap(k, e, nd, stk);
+                if (cls == RT_WK_BOX) rt_walk_box<Cfg, false, NS>(k, e, nd, stk);
+                else if (cls == RT_WK_LEAF) rt_walk_leaf<Cfg, NS>(sc, k, e, nd);
+                else if (cls == RT_WK_WRAP) rt_walk_wrap<NS>(k, e, nd, stk);
                 else parked = e;
             }
         }

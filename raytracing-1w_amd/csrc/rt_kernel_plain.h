@@ -55,6 +55,7 @@ struct LdsStack16 {
  * stack walk's dependent node fetches then cost LDS latency instead of L2/HBM latency */
 #define RT_LDS_NODE_CAP 1024
 struct LdsNodes {
+    static constexpr bool virt = false;
     const RtNodeHot* base;
     __device__ __forceinline__ RtNodeHot hot(uint32_t n) const { return base[n]; }
 };
@@ -432,12 +433,17 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
 #define RT_SS_KEYS 7u /* Lambertian with a solid colour, Lambertian with a texture, dielectric, metal, isotropic, terminal, retired (splitting the first by
                          the kind of primitive hit, rect or not: measured, no difference) */
 /* PW: the walk is the pair walk of sphere scenes (rt_walk_pair.h; CAP = its stack entries per lane), else the one-entry-per-step walk */
-template <class Cfg, int CAP, int PARTS, bool PW = false>
+/* HC > 0: the walk reads the scene's WALK TABLE (rt_walk_table.h; the context keeps it behind the node array, RT_WT_OFFSET) and keeps its
+ * first HC records -- the most visited nodes -- in LDS: final_scene's 256 most visited nodes take 70 % of the visits, and a 64-byte
+ * record read from LDS costs an eighth of what the four divergent 16-byte lane-loads cost the vector L1, which paces this walk. */
+template <class Cfg, int CAP, int PARTS, bool PW = false, int HC = 0>
 __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const RtFrame& f, rt_f64* __restrict__ partial,
                                                   unsigned long long* __restrict__ counters, const RtPwView* pwp = nullptr) {
     static_assert(!Cfg::sweep && RT_WALK_MODE == 0, "stack-walk variants only");
+    static_assert(!(PW && HC > 0), "the pair walk has its own records");
     constexpr int RT_SS_PER = (RT_XCH_QW + PARTS - 1) / PARTS;
     __shared__ uint32_t stack_mem[PW ? 1 : CAP * RT_BLOCK];
+    __shared__ RtNodeHot hc_mem[HC > 0 ? HC : 1];
 #if defined(RT_HAVE_PW)
     __shared__ uint32_t pw_ref[PW ? CAP * RT_BLOCK : 1];
     __shared__ float pw_ent[PW ? CAP * RT_BLOCK : 1];
@@ -463,6 +469,19 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
     stk.sp = 0;
     RtGlobalNodes ns;
     ns.p = sc.nodes;
+    typename std::conditional<(HC > 0), RtWalkNodes, RtGlobalNodes>::type wn; /* where the WALK reads its records */
+    if constexpr (HC > 0) {
+        const RtNodeHot* table = reinterpret_cast<const RtNodeHot*>(reinterpret_cast<const unsigned char*>(sc.nodes) + RT_WT_OFFSET(sc.n_nodes));
+        const uint32_t nc = sc.n_nodes < (uint32_t)HC ? sc.n_nodes : (uint32_t)HC;
+        const uint4* src = reinterpret_cast<const uint4*>(table);
+        uint4* dst = reinterpret_cast<uint4*>(hc_mem);
+        for (uint32_t i = threadIdx.x; i < nc * 4u; i += RT_BLOCK) dst[i] = src[i];
+        __syncthreads();
+        wn.lds = hc_mem; wn.glob = table; wn.nc = nc;
+    } else {
+        wn.p = sc.nodes;
+    }
+    const uint32_t walk_root = HC > 0 ? 0u : sc.root; /* the root's walk id is 0 */
     const unsigned long long n_items = rt_item_count(f);
     const unsigned long long npix = (unsigned long long)f.tile_w * f.tile_h;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -620,7 +639,7 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
             segs += path.depth_left != 0u ? 1ull : 0ull;
             w_best_t = RT_INF; w_best_prim = RT_NONE; w_best_scope = RT_NONE; w_scope = RT_NONE;
             if (path.depth_left != 0u) {
-                stk.push(sc.root); walking = true;
+                stk.push(walk_root); walking = true;
 #if RT_MEDIA_PREFILL
                 if (Cfg::media) rt_rng_fill(path.rng);
 #endif
@@ -647,24 +666,24 @@ __device__ __forceinline__ void rt_render_ss_body(const RtSceneView& sc, const R
     } else out = (n) > stop_at;
 #define RT_SS_BOX_STEPS_HERE()                                                                                      \
     if constexpr (RT_SS_BOX_STEPS(Cfg) > 0 && RT_SLICE_BOX_RUN && (!Cfg::ordered || RT_SLICE_BOX_RUN_ORDERED)) { \
-        rt_walk_box_run<Cfg, RT_SS_BOX_STEPS(Cfg)>(ns, k, stk);                                                  \
+        rt_walk_box_run<Cfg, RT_SS_BOX_STEPS(Cfg)>(wn, k, stk);                                                  \
     } else if constexpr (RT_SS_BOX_STEPS(Cfg) > 0) {                                                             \
         bool between_boxes = true;                                                                                  \
         for (int extra = 0; extra < RT_SS_BOX_STEPS(Cfg); ++extra)                                               \
-            if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(ns, k, stk);          \
+            if (between_boxes && !rt_walk_done(k, stk)) between_boxes = rt_walk_box_step<Cfg>(wn, k, stk);          \
     }
             for (;;) {
                 const bool more = !rt_walk_done(k, stk);
                 bool on_; { const uint32_t n_ = (uint32_t)__popcll(__ballot(more)); RT_SS_GOES_ON(n_, on_) }
                 if (!on_) break;
-                if (more) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk);
-                if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, ns, k, path.rng, stk); }
+                if (more) rt_walk_step<Cfg, true>(sc, wn, k, path.rng, stk);
+                if constexpr (RT_SLICE_TWO_STEPS(Cfg)) { if (!rt_walk_done(k, stk)) rt_walk_step<Cfg, true>(sc, wn, k, path.rng, stk); }
                 RT_SS_BOX_STEPS_HERE()
                 if constexpr (Cfg::media && RT_SLICE_HEAVY_EVERY > 1) {
                     const bool more2 = !rt_walk_done(k, stk);
                     { const uint32_t n_ = (uint32_t)__popcll(__ballot(more2)); RT_SS_GOES_ON(n_, on_) }
                     if (!on_) break;
-                    if (more2) rt_walk_light_step<Cfg>(sc, ns, k, stk);
+                    if (more2) rt_walk_light_step<Cfg>(sc, wn, k, stk);
                     RT_SS_BOX_STEPS_HERE()
                 }
             }

@@ -58,12 +58,13 @@ __device__ __forceinline__ void rt_walk_box_run(const NS& ns, RtWalk& k, Stack& 
         const bool take = node && km <= RT_BVH1;
         const bool two = km == RT_BVH2;
         const bool hit = take && rt_walk_slab<Cfg, false>(k, nd);
-        uint32_t first = e + 1u, second = nd.b; /* left child = the next node in pre-order, then the right one: bvh.rs:38-47 */
+        const uint32_t left = rt_ns_child<NS>(e, nd);
+        uint32_t first = left, second = nd.b; /* left child (the next node in pre-order), then the right one: bvh.rs:38-47 */
         if constexpr (Cfg::ordered) {
             const uint32_t ord = (nd.kind >> RT_BVH_ORDER_SHIFT) & RT_BVH_ORDER_MASK;
             const double da = ord == 1u ? k.cur.d.x : (ord == 2u ? k.cur.d.y : k.cur.d.z);
             const bool left_lower = (nd.kind & RT_BVH_LEFT_LOWER) != 0u;
-            if (two && ord != 0u && ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower))) { first = nd.b; second = e + 1u; }
+            if (two && ord != 0u && ((da < RT_R(0.0) && left_lower) || (da > RT_R(0.0) && !left_lower))) { first = nd.b; second = left; }
         }
         stk.put(sp > 0 ? sp - 1 : 0, second); /* the top's own slot: the second child of a hit BVHChild::Two, dead otherwise */
         sp += hit ? (two ? 1 : 0) : (take ? -1 : 0);

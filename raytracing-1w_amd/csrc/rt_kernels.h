@@ -29,6 +29,46 @@ __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss(
     rt_render_ss_body<Cfg, CAP, PARTS>(sc, f, partial, counters);
 }
 
+/* the same with the scene's most visited nodes in LDS (rt_walk_table.h): scenes whose walk needs at most RT_SS_HC_CAP stack entries -- the
+ * 16 KB that the shorter stack columns leave are the cache */
+#define RT_SS_HC_CAP 16
+#define RT_SS_HC_RECORDS 256
+template <class Cfg>
+__global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss_hc(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+                                                                              unsigned long long* __restrict__ counters) {
+    rt_render_ss_body<Cfg, RT_SS_HC_CAP, 3, false, RT_SS_HC_RECORDS>(sc, f, partial, counters);
+}
+
+/* node visits of a small render, counted per node: what the context ranks the walk table by (context.hip) */
+struct RtCountingNodes {
+    static constexpr bool virt = false;
+    const RtNode* p;
+    uint32_t* visits;
+    __device__ RtNodeHot hot(uint32_t n) const { atomicAdd(&visits[n], 1u); return *reinterpret_cast<const RtNodeHot*>(p + n); }
+};
+struct RtLocalStack {
+    uint32_t e[RT_STACK_CAP + 2];
+    int sp;
+    __device__ void push(uint32_t v) { e[sp++] = v; }
+    __device__ void poke(int above, uint32_t v) { e[sp + above] = v; }
+    __device__ uint32_t pop() { return e[--sp]; }
+};
+__global__ void rt_visit_count_kernel(RtSceneView sc, RtFrame f, uint32_t* __restrict__ visits) {
+    const unsigned long long n = (unsigned long long)f.tile_w * f.tile_h * f.spp;
+    RtCountingNodes ns; ns.p = sc.nodes; ns.visits = visits;
+    RtLocalStack stk; stk.sp = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t s = (uint32_t)(i % f.spp);
+        const unsigned long long pix = i / f.spp;
+        RtPath path;
+        rt_path_begin(sc, f, (uint32_t)(pix % f.tile_w), (uint32_t)(pix / f.tile_w), s, path);
+        while (path.alive) {
+            const RtTrace tr = rt_path_trace<RtCfgV3>(sc, ns, path, stk);
+            rt_path_shade<RtCfgV3>(sc, path, tr);
+        }
+    }
+}
+
 /* the same for sphere scenes: the pair walk in slices + the reordering of the finished paths (RT_PW_SS_STACK, rt_kernel_plain.h) */
 #ifndef RT_SS_CAP
 #define RT_SS_CAP RT_STACK_CAP /* stack entries per lane of the stack-walk kernels that reorder (experiments: 16 for four workgroups per CU) */

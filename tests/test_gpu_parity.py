@@ -807,6 +807,44 @@ def test_sphere_media_kernels_are_bit_identical(rt, gpu_ctx_factory):
     ctx.close()
 
 
+def test_node_cache_kernels_are_bit_identical(rt, gpu_ctx_factory):
+    """Big scenes' stack-walk kernels read their node records through the scene's WALK TABLE (csrc/rt_walk_table.h) and keep its first 256
+    records -- the most visited nodes, ranked by a visit count the context takes at creation -- in LDS (stats.sorted bit 10 = 1024).
+    Where a record is read from changes nothing: same frame and segment count as the same kernels without the cache
+    (RT1W_NO_NODE_CACHE) and as the CPU build of the core walking the node array -- final_scene on the three trees and the near-far
+    order (sphere-media builds of V3 / V4), its general-media build (RT1W_CLASSIC_WALK), random_scene's one-entry-per-step renders
+    (V5, V2), tiles, sample offsets, tiny frames, several samples per work item."""
+    for build, near_far in (("best_axis", False), ("reference", False), ("sah", True)):
+        sc = rt.Scene.reference(7, build_seed=1).set_bvh_build(build)
+        if near_far:
+            sc.set_walk_order(True)
+        ctx = gpu_ctx_factory(sc)
+        for W, H, spp, kw in ((64, 64, 6, {}), (320, 320, 3, {}), (13, 9, 5, {}), (96, 80, 8, dict(tile=(16, 8, 50, 37), sample_offset=3)),
+                              (48, 48, 24, dict(chunk=8)), (64, 64, 6, dict(classic_walk=True))):
+            if near_far and "classic_walk" in kw:
+                continue  # the near-far order's general-media build has no reordering form: the plain kernel runs, with or without the flag
+            a, sa = ctx.render(W, H, spp, **kw)
+            b, sb = ctx.render(W, H, spp, no_node_cache=True, **kw)
+            assert sa["sorted"] & 1024 and sa["sorted"] & 512 and not (sb["sorted"] & 1024) and sb["sorted"] & 512, (sa["sorted"], sb["sorted"])
+            assert bool(sa["sorted"] & 256) == ("classic_walk" not in kw)
+            assert sa["variant"] == sb["variant"] == (4 if near_far else 3)
+            assert sa["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True), (build, near_far, W, H, spp, kw)
+        cpu, sc_ = orc.flat_render(sc, 64, 64, 6, chunk=sc.default_chunk(64, 64, 6))
+        a, sa = ctx.render(64, 64, 6)
+        assert sa["sorted"] & 1024 and sa["segments"] == sc_["segments"] and np.array_equal(a, cpu, equal_nan=True), (build, near_far)
+        ctx.close()
+    sc = rt.Scene.reference(0, build_seed=1, aspect_ratio=1.5)
+    ctx = gpu_ctx_factory(sc)
+    base, sb = ctx.render(96, 64, 6)
+    assert sb["sorted"] & 128 and not (sb["sorted"] & 1024)       # the pair walk has its own records
+    for kw in (dict(classic_walk=True), dict(variant=2)):
+        a, sa = ctx.render(96, 64, 6, **kw)
+        b, sb2 = ctx.render(96, 64, 6, no_node_cache=True, **kw)
+        assert sa["sorted"] & 1024 and not (sb2["sorted"] & 1024) and not (sa["sorted"] & 128), (kw, sa["sorted"], sb2["sorted"])
+        assert sa["segments"] == sb2["segments"] == sb["segments"] and np.array_equal(a, b, equal_nan=True) and np.array_equal(a, base, equal_nan=True), kw
+    ctx.close()
+
+
 def test_slice_sorted_kernels_are_bit_identical(rt, gpu_ctx_factory):
     """The default kernels of sphere-media scenes (final_scene) reorder the paths whose walk has ended across the workgroup at the
     end of every slice of the stack walk (rt_kernel_plain.h: rt_render_ss_body; stats.sorted bit 9 = 512): which lane shades a

@@ -34,6 +34,15 @@ SCRIPT = textwrap.dedent("""
     for rays in (pw.rays_for(1, 1500, rng), pw.nasty(pw.rays_for(1, 1500, rng), rng)):
         t, prim, rt_, rprim, flags = pw.pair_walk(B, sc0, rays, stack_cap=12, seed=5)
         assert not (flags & 2).any() and np.array_equal(prim, rprim)
+    # the walk over the walk table (rt_walk_table.h) with an arbitrary ranking, finite and non-finite rays
+    import test_walk_table_host as wt
+    for arm, variant in ((7, 103), (6, 3)):
+        scw = rt.Scene.reference(arm, build_seed=1)
+        rays = wt.scene_rays(scw, 1500, rng)
+        visits = rng.integers(0, 50, scw.info()['n_nodes']).astype(np.uint32)
+        for rr in (rays, wt.nasty(rays, rng)):
+            t, prim, scope, flags, _ = wt.walk_table_check(B, scw, rr, visits=visits, nc=64, variant=variant)
+            assert not (flags & 3).any()
     print('SANITIZED-OK')
 """)
 
