@@ -81,7 +81,13 @@ uint64_t fnv1a(uint64_t h, const std::string& s) { return fnv1a(h, s.data(), s.s
  * tools/stamps.py), plus the space-separated words of RT1W_JIT_EXTRA_OPTS (compiler-flag experiments; never anything that
  * changes floating-point semantics).  All of them go into the cache key. */
 std::vector<std::string> options() {
-    std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1"};
+    /* -structurizecfg-skip-uniform-regions: the unrolled sweep is a chain of wave-uniform branches ("is any lane of the wave at this
+     * node?") around divergent bodies; left alone, StructurizeCFG rewrites the uniform ones as well and they cost exec-mask
+     * bookkeeping.  Measured on the Cornell kernel: 155 VGPRs instead of 158, +2.0 % (profiles/r04_jit_options.txt: 39 backend
+     * options and their combinations; nothing else is worth a flag).  Codegen only: the frames are the same bits (every GPU parity
+     * test runs these kernels). */
+    std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1",
+                                  "-mllvm", "-structurizecfg-skip-uniform-regions=1"};
     if (std::getenv("RT1W_JIT_STAMPS")) o.push_back("-DRT_STAMPS=1");
     if (const char* e = std::getenv("RT1W_JIT_EXTRA_OPTS")) {
         std::string w;
