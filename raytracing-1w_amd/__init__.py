@@ -430,11 +430,11 @@ class Context:
         return out, {n: getattr(st, n) for n, _ in Stats._fields_}
 
     def render_rows(self, width, height, spp, strip_rows=0, u8=False, progress=None, max_depth=50, tile=None,
-                    sample_offset=0, global_seed=0, chunk=0, out_sum=False, out=None):
+                    sample_offset=0, global_seed=0, chunk=0, out_sum=False, out=None, no_node_cache=False):
         """Strip-wise render from the top row down with D2H overlapped (rt1w_render_rows).  `progress(rows_done, rows_total)`
         is called as strips land; returning a true value cancels (raises Rt1wError with code ERR_CANCELLED).
         Returns the same arrays as render() (u8=False) or render_u8() (u8=True)."""
-        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum)
+        p = self._params(width, height, spp, max_depth, tile, sample_offset, global_seed, chunk, out_sum, no_node_cache=no_node_cache)
         if out is None:
             out = np.empty((p.tile_h, p.tile_w, 3), dtype=np.uint8 if u8 else np.float64)
         assert out.flags.c_contiguous and out.shape == (p.tile_h, p.tile_w, 3) and out.dtype == (np.uint8 if u8 else np.float64)

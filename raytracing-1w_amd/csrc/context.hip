@@ -201,6 +201,7 @@ bool upload_nodes(void** dst, const std::vector<RtNode>& nodes) {
  * cached kernels have, simply keeps the kernels without the cache. */
 bool build_walk_table(rt1w_context* c, const std::vector<RtNode>& nodes, uint32_t root, uint32_t stack_need, std::string& why) {
     const uint32_t n = (uint32_t)nodes.size();
+    if (n == 0u) { why = "no nodes"; return false; }
     if (stack_need > (uint32_t)RT_SS_HC_CAP) { why = "the walk needs more than RT_SS_HC_CAP stack entries"; return false; }
     uint32_t* d_visits = nullptr;
     std::vector<uint32_t> visits(n, 0u);
@@ -722,9 +723,10 @@ int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out) 
             }
         }
     } else c->pw_why = "not a wrapper-free, media-free scene of more than 64 nodes, or its tree is deeper than the pair walk's stack";
-    if (c->variant >= 2) {
-        /* a stack-walk scene: its walk table and the kernels that keep the table's head in LDS (sphere scenes run the pair walk by
-         * default; the table serves their one-entry-per-step renders, RT1W_CLASSIC_WALK) */
+    {
+        /* the walk table and the kernels that keep its head in LDS: what a stack-walk scene's renders run (sphere scenes run the pair
+         * walk by default; the table serves their one-entry-per-step renders, RT1W_CLASSIC_WALK).  Built for every scene: a small
+         * scene's renders with a forced stack-walk variant (tests) go through it as well */
         std::string why;
         c->walk_table = build_walk_table(c, s->flat_nodes, s->flat_root, s->stack_need, why);
         if (c->walk_table) {

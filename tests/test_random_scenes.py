@@ -55,6 +55,11 @@ def test_random_scene_graphs_on_the_gpu(rt, gpu_ctx_factory):
         for v in (1, 3):
             f, sf = ctx.render(W, H, spp, variant=v)
             assert np.array_equal(f, g, equal_nan=True), (seed, v)
+        # the forced stack walk reads its nodes through the walk table, the most visited records from LDS (bit 10), general media
+        # boundaries included; without the cache: the same bits
+        assert bool(sf["sorted"] & 1024) == (info["stack_need"] <= 16), (seed, sf["sorted"], info)
+        f2, sf2 = ctx.render(W, H, spp, variant=3, no_node_cache=True)
+        assert not (sf2["sorted"] & 1024) and sf2["segments"] == sg["segments"] and np.array_equal(f2, g, equal_nan=True), (seed, "no node cache")
         # the wavefront form on the same graphs (forced stack-walk variant: wrappers, media, nested BVHs through the
         # vote-scheduled trace kernel with LDS-resident walk records, the shade kernel and the finish kernel)
         try:
