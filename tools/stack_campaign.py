@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 W, H, spp = (int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (96, 64, 6)
 done = bad = 0
 t0 = time.time()
-stats = {"media": 0, "moving": 0, "wrappers": 0, "V5": 0}
+stats = {"media": 0, "moving": 0, "wrappers": 0, "V5": 0, "node_cache_renders": 0, "renders": 0}
 for seed in range(7000, 7000 + n):
     prod, _ = random_scene_pair(seed)
     for mode in ("reference", "sah", "sah+near-far"):
@@ -29,6 +29,7 @@ for seed in range(7000, 7000 + n):
             got, sg = c.render(W, H, spp, variant=v)
             ok = sg["variant"] == v and sg["segments"] == sw["segments"] and np.array_equal(got, want, equal_nan=True)
             bad += 0 if ok else 1
+            stats["renders"] += 1; stats["node_cache_renders"] += 1 if (sg["sorted"] & 1024) else 0
             if not ok:
                 print("MISMATCH seed", seed, mode, "variant", v, info, flush=True)
         c.close()
