@@ -264,7 +264,8 @@ def git_head():
 
 KERNEL_SOURCES = ("include/rt1w_num.h", "raytracing-1w_amd/csrc/rt_flat.h", "raytracing-1w_amd/csrc/rt_core.h",
                   "raytracing-1w_amd/csrc/rt_kernel_sorted.h", "raytracing-1w_amd/csrc/rt_kernel_plain.h",
-                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/rt_kernels.h", "raytracing-1w_amd/csrc/rt_walk_table.h")
+                  "raytracing-1w_amd/csrc/rt_walk_pair.h", "raytracing-1w_amd/csrc/rt_kernels.h", "raytracing-1w_amd/csrc/rt_walk_table.h",
+                  "raytracing-1w_amd/csrc/Makefile") # the Makefile: the compiler options the kernels are built with
 
 
 def kernel_sources_id():
