@@ -199,6 +199,7 @@ bool upload_nodes(void** dst, const std::vector<RtNode>& nodes) {
  * with a kernel that counts the node fetches (rt_visit_count_kernel: a few ms, once per context).  Which nodes the kernels keep in LDS
  * changes where a record is read from and nothing else -- a scene whose table cannot be built, or whose walk needs more stack than the
  * cached kernels have, simply keeps the kernels without the cache. */
+static_assert(RT_SS_HC_RECORDS == (int)RT_WT_CACHE_MAX, "the kernels cache exactly the records the table ranks");
 bool build_walk_table(rt1w_context* c, const std::vector<RtNode>& nodes, uint32_t root, uint32_t stack_need, std::string& why) {
     const uint32_t n = (uint32_t)nodes.size();
     if (n == 0u) { why = "no nodes"; return false; }
