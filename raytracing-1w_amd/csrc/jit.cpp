@@ -87,7 +87,11 @@ std::vector<std::string> options() {
      * options and their combinations; nothing else is worth a flag).  Codegen only: the frames are the same bits (every GPU parity
      * test runs these kernels). */
     std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_JIT=1",
-                                  "-mllvm", "-structurizecfg-skip-uniform-regions=1"};
+                                  "-mllvm", "-structurizecfg-skip-uniform-regions=1",
+                                  /* the hipcc-built kernels' other options (csrc/Makefile: KOPTS): neutral at three waves per SIMD,
+                                   * but they take the Cornell kernel from 155 to 143 VGPRs -- what makes the fourth wave pay (jit_source) */
+                                  "-mllvm", "-spec-exec-max-speculation-cost=0", "-mllvm", "-simplifycfg-hoist-common=false",
+                                  "-mllvm", "-amdgpu-sdwa-peephole=0"};
     if (std::getenv("RT1W_JIT_STAMPS")) o.push_back("-DRT_STAMPS=1");
     if (const char* e = std::getenv("RT1W_JIT_EXTRA_OPTS")) {
         std::string w;
@@ -172,8 +176,17 @@ std::string jit_source(const rt1w_scene& s, bool f32) {
     src += "/* generated by librt1w (jit.cpp) for one scene topology */\n";
     if (f32) /* the single-precision build of the same kernel: context_f32.hip's switch, here for the run-time compiler */
         src += "#include <stdint.h>\n#include <type_traits>\ntypedef double rt_f64;\n#define RT_F32 1\n#define double float\n";
-    else
+    else {
+        /* Four waves per SIMD (128 VGPRs) and the exchange in two rounds (27 KB of LDS per workgroup, four workgroups per CU) for the
+         * scenes whose shading fits: no Perlin-noise and no checker texture.  With the options below the Cornell kernel needs 143 VGPRs
+         * at three waves, so the fourth wave costs few spills and hides what three cannot: Cornell 2362 -> 2620 Mpaths/s (+11 %),
+         * cornel_smoke +12 %, earth +8 %; the noise / checker scenes lose 2-6 % that way and keep three waves and one round
+         * (profiles/r04_jit_options.txt) */
+        bool heavy_tex = false;
+        for (const RtTexture& t : s.textures) if (t.kind == RT_TEX_NOISE || t.kind == RT_TEX_CHECKER) heavy_tex = true;
+        if (!heavy_tex) src += "#define RT_XCH_PARTS 2\n#define RT_SORT_WAVES_OVERRIDE 4\n";
         src += "#include \"rt1w_num.h\"\n"; /* declares rt_f64 */
+    }
     src += "#include \"rt_kernel_sorted.h\"\n";
     src += "struct TopoJit {\n";
     src += "    static constexpr uint32_t n = " + std::to_string(N.size()) + "u, root = " + std::to_string(s.flat_root) + "u;\n";

@@ -1,4 +1,4 @@
-"""C3 residue experiment: the exchange in RT_XCH_PARTS rounds (less LDS per workgroup) x waves per SIMD, on the specialised
+"""(XCH_ARMS=1,2,3,4,5,6 selects the scene arms; default 5,6.)  C3 residue experiment: the exchange in RT_XCH_PARTS rounds (less LDS per workgroup) x waves per SIMD, on the specialised
 Cornell and cornel_smoke kernels; every setting in a child process, frames hashed against the default build's."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +7,7 @@ import sys, os, hashlib, importlib
 sys.path.insert(0, %r)
 rt = importlib.import_module("raytracing-1w_amd")
 out = []
-for arm in (5, 6):
+for arm in [int(a) for a in os.environ.get("XCH_ARMS", "5,6").split(",")]:
     ctx = rt.Context(rt.Scene.reference(arm), 0)
     info = ctx.specialise()
     g, s = ctx.render(96, 96, 16)
