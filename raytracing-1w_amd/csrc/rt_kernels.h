@@ -32,11 +32,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss(
 /* the same with the scene's most visited nodes in LDS (rt_walk_table.h): scenes whose walk needs at most RT_SS_HC_CAP stack entries -- the
  * 16 KB that the shorter stack columns leave are the cache */
 #define RT_SS_HC_CAP 16
+#ifndef RT_SS_HC_RECORDS
 #define RT_SS_HC_RECORDS 256
+#endif
+#ifndef RT_SS_HC_PARTS
+#define RT_SS_HC_PARTS 3
+#endif
 template <class Cfg>
 __global__ __launch_bounds__(RT_BLOCK, RT_STACK_WAVES) void rt_render_kernel_ss_hc(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                                               unsigned long long* __restrict__ counters) {
-    rt_render_ss_body<Cfg, RT_SS_HC_CAP, 3, false, RT_SS_HC_RECORDS>(sc, f, partial, counters);
+    rt_render_ss_body<Cfg, RT_SS_HC_CAP, RT_SS_HC_PARTS, false, RT_SS_HC_RECORDS>(sc, f, partial, counters);
 }
 
 /* node visits of a small render, counted per node: what the context ranks the walk table by (context.hip) */

@@ -29,7 +29,9 @@
 #include <vector>
 #include "rt_core.h"
 
+#ifndef RT_WT_CACHE_MAX
 #define RT_WT_CACHE_MAX 256u /* records the kernels keep in LDS (16 KB) */
+#endif
 
 struct RtWalkTable {
     std::vector<RtNodeHot> rec;   /* [n_nodes], walk-id order */
