@@ -184,7 +184,8 @@ std::string jit_source(const rt1w_scene& s, bool f32) {
          * (profiles/r04_jit_options.txt) */
         bool heavy_tex = false;
         for (const RtTexture& t : s.textures) if (t.kind == RT_TEX_NOISE || t.kind == RT_TEX_CHECKER) heavy_tex = true;
-        if (!heavy_tex) src += "#define RT_XCH_PARTS 2\n#define RT_SORT_WAVES_OVERRIDE 4\n";
+        if (!heavy_tex) /* (a -DRT_SORT_WAVES_OVERRIDE=3 -DRT_XCH_PARTS=1 in RT1W_JIT_EXTRA_OPTS builds the three-wave form: A/B tools) */
+            src += "#ifndef RT_SORT_WAVES_OVERRIDE\n#define RT_XCH_PARTS 2\n#define RT_SORT_WAVES_OVERRIDE 4\n#endif\n";
         src += "#include \"rt1w_num.h\"\n"; /* declares rt_f64 */
     }
     src += "#include \"rt_kernel_sorted.h\"\n";
