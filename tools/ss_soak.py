@@ -27,5 +27,20 @@ for arm, aspect, W, H, spp, sah in ((7, 1.0, 800, 800, 12, False), (7, 1.0, 800,
         bad += (h != want) or (st["segments"] != sr["segments"])
     print(f"arm {arm}{' SAH + near-far' if sah else ''} {W}x{H}x{spp}: {N} renders, {len(seen)} distinct frame(s), equal to the plain kernel's: {list(seen) == [want]}", flush=True)
     ctx.close()
+# the specialised kernels (four waves per SIMD, exchange in two rounds for Cornell / cornel_smoke; three waves for the noise scenes):
+# N renders, one frame, equal to the generic plain kernel's
+for arm, W, H, spp in ((5, 600, 600, 20), (6, 600, 600, 20), (2, 400, 225, 20), (5, 203, 157, 9)):
+    ctx = rt.Context(rt.Scene.reference(arm), 0)
+    ref, sr = ctx.render(W, H, spp, unsorted=True, generic=True, chunk=rt.default_chunk(W, H, spp))
+    want = hashlib.sha256(ref.tobytes()).hexdigest()
+    seen = {}
+    for i in range(N):
+        img, st = ctx.render(W, H, spp)
+        assert st["sorted"] & 4
+        h = hashlib.sha256(img.tobytes()).hexdigest()
+        seen[h] = seen.get(h, 0) + 1
+        bad += (h != want) or (st["segments"] != sr["segments"])
+    print(f"arm {arm} specialised {W}x{H}x{spp}: {N} renders, {len(seen)} distinct frame(s), equal to the generic plain kernel's: {list(seen) == [want]}", flush=True)
+    ctx.close()
 print("mismatches", bad)
 sys.exit(1 if bad else 0)
