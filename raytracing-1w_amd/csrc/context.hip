@@ -142,6 +142,7 @@ struct rt1w_context {
     hipModule_t jit_mod = nullptr;
     hipFunction_t jit_fn = nullptr;
     int jit_grid = 0;
+    int jit_block = RT_SORT_BLOCK; /* the specialised kernel's workgroup size = its sort domain (its __launch_bounds__; experiments build it for 512) */
     uint32_t jit_vgprs = 0;
     bool jit_failed = false; /* a compile was tried and failed: do not try again on this context */
     /* the same for RT1W_PRECISION_F32: loaded / compiled at the first f32 render of a specialised context */
@@ -377,7 +378,7 @@ int render_plan(rt1w_context* c, const rt1w_render_params* p, RtLaunch& L) {
     }
     L.variant = variant;
     L.jit = c->jit_fn != nullptr && !(p->flags & (RT1W_GENERIC | RT1W_UNSORTED | RT1W_LDS_NODES)) && !((p->flags >> 8) & 0xFFu);
-    if (L.jit) { L.sorted = true; L.cached = false; L.grid = c->jit_grid; L.block = RT_SORT_BLOCK; return RT1W_OK; }
+    if (L.jit) { L.sorted = true; L.cached = false; L.grid = c->jit_grid; L.block = c->jit_block; return RT1W_OK; }
     /* sphere scenes: the pair walk (same frames, bit for bit), unless the caller asks for the one-entry-per-step walk */
     if (c->pw_ok && variant == 5 && !(p->flags & (RT1W_CLASSIC_WALK | RT1W_LDS_NODES | RT1W_WAVEFRONT))) {
         L.pw = true; L.sorted = false; L.cached = false; L.grid = c->pw_grid; L.block = RT_BLOCK;
@@ -512,8 +513,10 @@ int specialise(rt1w_context* c, bool allow_compile, rt1w::JitInfo& info) {
     if (!hip_ok(hipModuleGetFunction(&fn, c->jit_mod, "rt_jit_sorted"), "hipModuleGetFunction")) {
         (void)hipModuleUnload(c->jit_mod); c->jit_mod = nullptr; return RT1W_ERR_DEVICE;
     }
-    int per_cu = 0;
-    if (!hip_ok(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RT_SORT_BLOCK, 0), "occupancy query")) per_cu = 1;
+    int per_cu = 0, max_threads = 0;
+    c->jit_block = RT_SORT_BLOCK;
+    if (hipFuncGetAttribute(&max_threads, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, fn) == hipSuccess && (max_threads == 512 || max_threads == 128)) c->jit_block = max_threads;
+    if (!hip_ok(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, c->jit_block, 0), "occupancy query")) per_cu = 1;
     if (per_cu < 1) per_cu = 1;
     hipDeviceProp_t prop;
     if (!hip_ok(hipGetDeviceProperties(&prop, c->device), "hipGetDeviceProperties")) { (void)hipModuleUnload(c->jit_mod); c->jit_mod = nullptr; return RT1W_ERR_DEVICE; }
