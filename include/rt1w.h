@@ -192,6 +192,9 @@ int64_t rt1w_scene_copy_flat(const rt1w_scene* s, int what, void* buf, uint64_t 
 /* ---- execution (replaces src/main.rs:957-1001) ---- */
 
 int rt1w_device_count(void);
+/* uploads the committed scene's flat arrays once (they are immutable afterwards); loads the scene-specialised kernel if the kernel
+ * cache has it; counts node visits in a 128 x 128 x 1 render of the scene's own camera (5-15 ms) to rank the records the stack-walk
+ * kernels keep in LDS (csrc/rt_walk_table.h) */
 int rt1w_context_create(int device_id, const rt1w_scene* s, rt1w_context** out);
 void rt1w_context_destroy(rt1w_context* c);
 
