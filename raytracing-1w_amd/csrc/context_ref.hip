@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #define RT_RNG_REFSTREAM 1
+#define RT_XCH_PARTS 2 /* the reordering kernels' exchange in two rounds: 27 KB of LDS per workgroup, room for a fourth workgroup per CU */
 
 namespace rtref {
 #include "rt1w_num.h"
@@ -40,8 +41,10 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void rt_render_kernel_ref(RtSceneView 
 }
 /* the reordering kernel (rt_kernel_sorted.h) on the reference's stream: RtCfgV0 for scenes of solid colours without media or moving
  * spheres (Cornell: what the reference's own PNG shows), the every-feature sweep otherwise */
+/* four waves per SIMD for the solid-colour build (128 VGPRs, 68 B of scratch: Cornell 600x600 603 -> 620 Mpaths/s, 4K 1428 -> 1560); the
+ * every-feature build would spill 300 B per lane there and keeps three */
 template <class Cfg>
-__global__ __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES(Cfg)) void rt_render_kernel_ref_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
+__global__ __launch_bounds__(RT_SORT_BLOCK, (Cfg::tex || Cfg::media || Cfg::msphere) ? RT_SORT_WAVES(Cfg) : 4) void rt_render_kernel_ref_sorted(RtSceneView sc, RtFrame f, double* __restrict__ partial,
                                                                                            unsigned long long* __restrict__ counters) {
     rt_render_sorted_body<Cfg>(sc, f, partial, counters);
 }
