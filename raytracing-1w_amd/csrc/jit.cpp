@@ -91,7 +91,9 @@ std::vector<std::string> options() {
                                   /* the hipcc-built kernels' other options (csrc/Makefile: KOPTS): neutral at three waves per SIMD,
                                    * but they take the Cornell kernel from 155 to 143 VGPRs -- what makes the fourth wave pay (jit_source) */
                                   "-mllvm", "-spec-exec-max-speculation-cost=0", "-mllvm", "-simplifycfg-hoist-common=false",
-                                  "-mllvm", "-amdgpu-sdwa-peephole=0"};
+                                  "-mllvm", "-amdgpu-sdwa-peephole=0",
+                                  /* no partial-redundancy elimination in GVN: Cornell +0.8 % (twice measured), the other arms +-0.5 % */
+                                  "-mllvm", "-enable-pre=0"};
     if (std::getenv("RT1W_JIT_STAMPS")) o.push_back("-DRT_STAMPS=1");
     if (const char* e = std::getenv("RT1W_JIT_EXTRA_OPTS")) {
         std::string w;

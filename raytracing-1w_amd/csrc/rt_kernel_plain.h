@@ -391,8 +391,10 @@ __device__ __forceinline__ void rt_render_plain_body(const RtSceneView& sc, cons
 #ifndef RT_SS_IDLE
 /* finished walks per wave (RT_SS_WG_SLICE: per workgroup, x 4) that end a slice.  Measured, kernel Mpaths/s: final_scene 800x800x100 32: 302,
  * 36: 304, 40: 306-309, 44: 304, 48: 302, 56: 282 (the plain kernel: 273); random_scene 1200x800x100 (pair walk) 32: 842, 40: 907, 48: 933,
- * 56: 925 (the plain kernel: 878) */
-#define RT_SS_IDLE(Cfg) (Cfg::media ? 40 : 48)
+ * 56: 925 (the plain kernel: 878)
+ * Again with round 4's tree, work items and compiler options (profiles/r04_ab.txt): random_scene 48: 1285, 52: 1297, 56: 1297, 60: 1280, 62: 1234;
+ * final_scene 36: 399.5, 40: 400.4, 44: 397.7 */
+#define RT_SS_IDLE(Cfg) (Cfg::media ? 40 : 54)
 #endif
 #ifndef RT_SS_BOX_STEPS
 /* box-only steps per round of these kernels: with the slice ended for the whole workgroup a shorter round pays (the stop is noticed sooner).
