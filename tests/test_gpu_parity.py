@@ -807,6 +807,27 @@ def test_sphere_media_kernels_are_bit_identical(rt, gpu_ctx_factory):
     ctx.close()
 
 
+def test_specialised_kernels_are_built_for_the_waves_their_shading_allows(rt, gpu_ctx_factory):
+    """jit.cpp builds a scene's specialised f64 kernel for four waves per SIMD (128 VGPRs, the exchange in two rounds, four workgroups per
+    CU) unless the scene has a noise or checker texture, whose shading code would spill at 128 and which keep three waves (168 VGPRs,
+    one round).  What a render computes does not depend on it: both forms against the CPU build of the core."""
+    grids = {}
+    for arm, four in ((5, True), (6, True), (3, True), (2, False), (1, False), (4, False)):
+        sc = rt.Scene.reference(arm, build_seed=1)
+        ctx = gpu_ctx_factory(sc)
+        info = ctx.specialise()
+        assert info["active"]
+        assert (info["vgprs"] <= 128) == four, (arm, info)
+        grids[arm] = info["grid"]
+        W, H, spp = (48, 48, 8) if arm != 3 else (48, 27, 8)
+        g, sg = ctx.render(W, H, spp)
+        assert sg["sorted"] & 4
+        b, sb = orc.flat_render(sc, W, H, spp, chunk=sg["chunk"])
+        assert sg["segments"] == sb["segments"] and np.array_equal(g, b, equal_nan=True), arm
+        ctx.close()
+    assert grids[5] * 3 == grids[2] * 4, grids  # four workgroups per CU against three
+
+
 def test_node_cache_kernels_are_bit_identical(rt, gpu_ctx_factory):
     """Big scenes' stack-walk kernels read their node records through the scene's WALK TABLE (csrc/rt_walk_table.h) and keep its first 256
     records -- the most visited nodes, ranked by a visit count the context takes at creation -- in LDS (stats.sorted bit 10 = 1024).
